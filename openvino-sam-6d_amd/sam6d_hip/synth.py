@@ -1,0 +1,146 @@
+"""Synthetic weights and inputs for the PEM/ISM matching path (no checkpoints exist offline).
+
+`pem_param_shapes()` lists the reference's state_dict keys/shapes for the hot-path sub-modules
+(verified against the reference modules by oracle/gen_golden.py), `make_pem_weights()` fills them
+deterministically from a seed with non-trivial values for every tensor (biases, LayerNorm/BatchNorm affine and
+running statistics included, so parity tests exercise them), and `config2_inputs()` is BASELINE.md's headline
+workload generator.
+"""
+import math
+
+import numpy as np
+import torch
+
+C = 256
+
+
+def _attn_layer(p, rpe):
+    out = []
+    names = ["proj_q", "proj_k", "proj_v"] + (["proj_p"] if rpe else [])
+    for n in names:
+        out += [(f"{p}.attention.attention.{n}.weight", (C, C)), (f"{p}.attention.attention.{n}.bias", (C,))]
+    out += [(f"{p}.attention.linear.weight", (C, C)), (f"{p}.attention.linear.bias", (C,)),
+            (f"{p}.attention.norm.weight", (C,)), (f"{p}.attention.norm.bias", (C,))]
+    out += _ffn(p)
+    return out
+
+
+def _ffn(p):
+    return [(f"{p}.output.expand.weight", (2 * C, C)), (f"{p}.output.expand.bias", (2 * C,)),
+            (f"{p}.output.squeeze.weight", (C, 2 * C)), (f"{p}.output.squeeze.bias", (C,)),
+            (f"{p}.output.norm.weight", (C,)), (f"{p}.output.norm.bias", (C,))]
+
+
+def _geo_transformer(p):
+    return _attn_layer(p + ".layers.0", True) + _attn_layer(p + ".layers.1", False)
+
+
+def pem_param_shapes(nblock=3):
+    """(key, shape) for geo_embedding / coarse_point_matching / fine_point_matching, reference naming."""
+    s = [("geo_embedding.embedding.div_term", (C // 2,)),
+         ("geo_embedding.proj_d.weight", (C, C)), ("geo_embedding.proj_d.bias", (C,)),
+         ("geo_embedding.proj_a.weight", (C, C)), ("geo_embedding.proj_a.bias", (C,))]
+    for m in ("coarse_point_matching", "fine_point_matching"):
+        s += [(f"{m}.bg_token", (1, 1, C)), (f"{m}.in_proj.weight", (C, C)), (f"{m}.in_proj.bias", (C,)),
+              (f"{m}.out_proj.weight", (C, C)), (f"{m}.out_proj.bias", (C,))]
+    for i in range(nblock):
+        s += _geo_transformer(f"coarse_point_matching.transformers.{i}")
+    for k in (1, 2):
+        dims = [6, 32, 64, 128]
+        for l in range(3):
+            q = f"fine_point_matching.PE.mlp{k}.layer{l}"
+            s += [(q + ".conv.weight", (dims[l + 1], dims[l], 1, 1))]
+            for n in ("weight", "bias", "running_mean", "running_var"):
+                s += [(f"{q}.normlayer.bn.{n}", (dims[l + 1],))]
+            s += [(f"{q}.normlayer.bn.num_batches_tracked", ())]
+    s += [("fine_point_matching.PE.mlp3.conv.weight", (C, C, 1)), ("fine_point_matching.PE.mlp3.conv.bias", (C,))]
+    for i in range(nblock):
+        t = f"fine_point_matching.transformers.{i}"
+        s += _geo_transformer(t + ".sparse_layer")
+        d = t + ".dense_layer"
+        s += [(f"{d}.attention.attention.scale", (1, 1, C))]
+        for n in ("proj_q", "proj_k", "proj_v"):
+            s += [(f"{d}.attention.attention.{n}.weight", (C, C)), (f"{d}.attention.attention.{n}.bias", (C,))]
+        s += [(f"{d}.attention.linear.weight", (C, C)), (f"{d}.attention.linear.bias", (C,)),
+              (f"{d}.attention.norm.weight", (C,)), (f"{d}.attention.norm.bias", (C,))]
+        s += _ffn(d)
+    return s
+
+
+def div_term(d_model=C):
+    """PEM/model/transformer.py:264-266 (same torch ops, so the buffer is bit-identical)."""
+    return torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+
+
+def make_pem_weights(seed=1, nblock=3):
+    """Deterministic CPU float32 weights for every key of pem_param_shapes()."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key, shape in pem_param_shapes(nblock):
+        leaf = key.rsplit(".", 1)[-1]
+        if key.endswith("div_term"):
+            t = div_term()
+        elif leaf == "num_batches_tracked":
+            t = torch.tensor(1, dtype=torch.int64)
+        elif leaf == "running_var":
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "bg_token":
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif leaf == "scale":
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif leaf == "weight" and len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        elif leaf == "weight":  # LayerNorm / BatchNorm gamma
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:  # biases, norm betas
+            t = 0.05 * torch.randn(shape, generator=g)
+        sd[key] = t.float() if t.dtype != torch.int64 else t
+    return sd
+
+
+def config2_inputs(B=32, seed=1, n_dense=2048, n_model=1024):
+    """BASELINE.md / SURVEY 8d config 2: synthetic (B,2048,3) clouds; CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g) - 0.5
+    dense_pm = u(B, n_dense, 3) + torch.tensor([0.0, 0.0, 8.0])
+    dense_po = u(B, n_dense, 3)
+    dense_fm = torch.randn(B, n_dense, C, generator=g)
+    dense_fo = torch.randn(B, n_dense, C, generator=g)
+    model = u(B, n_model, 3)
+    radius = torch.ones(B)
+    rand = torch.rand(B, 18000, generator=g)
+    return dict(dense_pm=dense_pm, dense_fm=dense_fm, dense_po=dense_po, dense_fo=dense_fo, radius=radius,
+                model=model, rand=rand)
+
+
+def random_rotation(g):
+    q = torch.randn(4, generator=g)
+    q = q / q.norm()
+    w, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=torch.float32)
+
+
+def kat_inputs(B=2, seed=3, n_dense=2048, n_model=1024, noise=0.0):
+    """Known-answer scene (SURVEY 8c KAT, extended to the full path): the observed cloud is the template
+    cloud under a known rigid motion (p_obs = p_tmpl @ R_gt^T + t_gt, permuted), and corresponding points carry
+    the same feature vector, so the matching is peaky and the discrete hypothesis selection is stable."""
+    g = torch.Generator().manual_seed(seed)
+    po = torch.rand(B, n_dense, 3, generator=g) - 0.5
+    fo = torch.randn(B, n_dense, C, generator=g)
+    Rg = torch.stack([random_rotation(g) for _ in range(B)])
+    tg = torch.stack([torch.tensor([0.1, -0.2, 2.0]) + 0.1 * torch.randn(3, generator=g) for _ in range(B)])
+    perm = torch.stack([torch.randperm(n_dense, generator=g) for _ in range(B)])
+    pm = torch.gather(po, 1, perm.unsqueeze(2).expand(B, n_dense, 3)) @ Rg.transpose(1, 2) + tg.unsqueeze(1)
+    fm = torch.gather(fo, 1, perm.unsqueeze(2).expand(B, n_dense, C))
+    if noise > 0:
+        pm = pm + noise * torch.randn(pm.shape, generator=g)
+    sub = torch.stack([torch.randperm(n_dense, generator=g)[:n_model] for _ in range(B)])
+    model = torch.gather(po, 1, sub.unsqueeze(2).expand(B, n_model, 3)).contiguous()
+    rand = torch.rand(B, 18000, generator=g)
+    return dict(dense_pm=pm.contiguous(), dense_fm=fm.contiguous(), dense_po=po, dense_fo=fo,
+                radius=torch.ones(B), model=model, rand=rand, R_gt=Rg, t_gt=tg)

@@ -1,0 +1,114 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle of SAM-6D's ISM template-scoring hot path.
+
+Functional torch-CPU restatement; each function cites the reference file:line it follows
+(ISM = SAM-6D/Instance_Segmentation_Model).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module.  Pinned by tests/test_oracle_golden.py against vectors captured from the reference's
+own model/loss.py, model/detector.py, utils/bbox_utils.py and utils/trimesh_utils.py (oracle/gen_golden.py).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def pairwise_similarity(query, reference):
+    """ISM/model/loss.py:27-44: cosine of every query (Nq,D) with every template (No,Nt,D) -> (Nq,No,Nt) in [0,1]."""
+    Nq = query.shape[0]
+    No, Nt = reference.shape[0], reference.shape[1]
+    refs = F.normalize(reference.clone().unsqueeze(0).repeat(Nq, 1, 1, 1), dim=-1)
+    qs = F.normalize(query.clone().unsqueeze(1).repeat(1, Nt, 1), dim=-1)
+    sims = [F.cosine_similarity(qs, refs[:, o], dim=-1) for o in range(No)]
+    return torch.stack(sims).permute(1, 0, 2).clamp(min=0.0, max=1.0)
+
+
+def semantic_score(query, ref_desc, aggregation="avg_5", confidence_thresh=0.2):
+    """ISM/model/detector.py:260-296 (+ best_template_pose :198-207).
+    Returns idx_selected (K,), pred_idx_objects (K,), semantic_score (K,), best_template (K,)."""
+    scores = pairwise_similarity(query, ref_desc)
+    if aggregation == "mean":
+        per_obj = scores.sum(-1) / scores.shape[-1]
+    elif aggregation == "median":
+        per_obj = torch.median(scores, dim=-1)[0]
+    elif aggregation == "max":
+        per_obj = torch.max(scores, dim=-1)[0]
+    elif aggregation == "avg_5":
+        per_obj = torch.topk(scores, k=5, dim=-1)[0].mean(-1)
+    else:
+        raise NotImplementedError
+    score, obj = torch.max(per_obj, dim=-1)
+    sel = torch.arange(len(score))[score > confidence_thresh]
+    pred_obj = obj[sel]
+    best_all = torch.max(scores[sel], dim=-1)[1]  # (K, No)
+    best = torch.gather(best_all, 1, pred_obj[:, None].repeat(1, best_all.shape[1]))[:, 0]
+    return sel, pred_obj, score[sel], best
+
+
+def appearance_score(best_pose, pred_obj, q_appe, ref_appe):
+    """ISM/model/detector.py:298-308 -> ISM/model/loss.py:52-62 (compute_straight)."""
+    ref = ref_appe[pred_obj, best_pose]  # (K, P, D)
+    sim = torch.matmul(q_appe, ref.permute(0, 2, 1))
+    mx = torch.max(sim, dim=-1).values
+    factor = torch.count_nonzero(q_appe.sum(dim=-1), dim=-1) + 1e-6
+    return (mx.sum(-1) / factor).clamp(min=0.0, max=1.0), ref
+
+
+def visible_ratio(q_appe, ref, thred=0.5):
+    """ISM/model/loss.py:64-76 (compute_visible_ratio)."""
+    sim = torch.matmul(q_appe, ref.permute(0, 2, 1)).max(1)[0]
+    valid = torch.count_nonzero(sim, dim=(1,)) + 1e-6
+    flt = sim * (sim > thred)
+    return torch.count_nonzero(flt, dim=(1,)) / valid
+
+
+def query_translation(masks, depth, K, depth_scale):
+    """ISM/model/detector.py:234-246 + ISM/utils/trimesh_utils.py:77-105: mean back-projected masked depth."""
+    md = masks * depth[None].repeat(masks.shape[0], 1, 1)
+    H, W = md.shape[1], md.shape[2]
+    u, v = torch.meshgrid(torch.arange(0, W), torch.arange(0, H), indexing="xy")
+    Z = md * depth_scale / 1000
+    X = (u - K[0, 2]) * Z / K[0, 0]
+    Y = (v - K[1, 2]) * Z / K[1, 1]
+    valid = Z > 0
+    X, Y, Z = X * valid, Y * valid, Z * valid
+    n = torch.count_nonzero(valid, dim=(1, 2)) + 1e-8
+    t = torch.vstack((X.sum((1, 2)) / n, Y.sum((1, 2)) / n, Z.sum((1, 2)) / n)).permute(1, 0)
+    return t.to(torch.float32)
+
+
+def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale):
+    """ISM/model/detector.py:209-232 -> image_vu (K, Npc, 2) int32 (x then y, clamped to the image)."""
+    R = poses[best_pose, 0:3, 0:3]
+    pc = pointcloud[pred_obj]
+    Nq, Np, _ = pc.shape
+    posed = torch.matmul(R, pc.permute(0, 2, 1)).permute(0, 2, 1)
+    posed = posed + query_translation(masks, depth, K, depth_scale)[:, None, :].repeat(1, Np, 1)
+    Kq = K[None].repeat(Nq, 1, 1).to(torch.float32)
+    homo = torch.bmm(Kq, posed.permute(0, 2, 1)).permute(0, 2, 1)
+    vu = (homo / homo[:, :, -1][:, :, None])[:, :, 0:2].to(torch.int)
+    H, W = depth.shape
+    vu[:, :, 0].clamp_(min=0, max=W - 1)
+    vu[:, :, 1].clamp_(min=0, max=H - 1)
+    return vu
+
+
+def compute_iou(bb_a, bb_b):
+    """ISM/utils/bbox_utils.py:197-222 -- including the quirk: any non-positive overlap => scalar 0.0."""
+    tl = torch.max(bb_a[:, 0:2], bb_b[:, 0:2])
+    br = torch.min(bb_a[:, 2:4], bb_b[:, 2:4])
+    wh_a = bb_a[:, 2:4] - bb_a[:, 0:2]
+    wh_b = bb_b[:, 2:4] - bb_b[:, 0:2]
+    wh = br - tl
+    if (wh > 0).all():
+        inter = wh[:, 0] * wh[:, 1]
+        return inter / (wh_a[:, 0] * wh_a[:, 1] + wh_b[:, 0] * wh_b[:, 1] - inter)
+    return 0.0
+
+
+def geometric_score(image_uv, boxes, q_appe, ref, thred=0.5):
+    """ISM/model/detector.py:310-322."""
+    vis = visible_ratio(q_appe, ref, thred)
+    xyxy = torch.concatenate((torch.min(image_uv, dim=1).values, torch.max(image_uv, dim=1).values), dim=-1)
+    return compute_iou(xyxy, boxes), vis
+
+
+def final_score(sem, appe, geo, vis):
+    """ISM/model/detector.py:384 / ISM/run_inference_custom.py:255."""
+    return (sem + appe + geo * vis) / (1 + 1 + vis)
