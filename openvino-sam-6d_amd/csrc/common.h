@@ -1,0 +1,88 @@
+// Shared helpers for the gfx950 (CDNA4, wave64) kernels of libsam6d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define SAM6D_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------------------
+// Every extern "C" entry point returns 0 on success, a negative SAM6D_E* code for bad arguments and a positive
+// hipError_t for runtime failures; sam6d_last_error() returns the text.  (The reference prints and exit(-1)s on a
+// CUDA launch failure, EXT/include/cuda_utils.h:42-51; SURVEY 8b asks for a checked error instead.)
+#define SAM6D_EINVAL (-1)
+#define SAM6D_ENOTIMPL (-2)
+
+void sam6d_set_error(const char* fmt, ...);
+
+#define SAM6D_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      sam6d_set_error(__VA_ARGS__);         \
+      return SAM6D_EINVAL;                  \
+    }                                       \
+  } while (0)
+
+#define SAM6D_LAUNCH_CHECK(name)                                                        \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      sam6d_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));           \
+      return (int)e__;                                                                  \
+    }                                                                                   \
+    return 0;                                                                           \
+  } while (0)
+
+#define SAM6D_LAUNCH_CHECK_CONT(name)                                                   \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      sam6d_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));           \
+      return (int)e__;                                                                  \
+    }                                                                                   \
+  } while (0)
+
+// ---- device helpers ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// squared distance in the torch-CPU K=3 matmul recipe (PEM/utils/model_utils.py:101-128):
+//   s = (p0*p0 + p1*p1) + p2*p2 (plain adds), xy = fma(x2,y2, fma(x1,y1, x0*y0)), d = max((sx - 2xy) + sy, 0)
+// The library is built with -ffp-contract=off, so only the explicit fmaf calls fuse.
+__device__ __forceinline__ float sqnorm3(float a, float b, float c) { return (a * a + b * b) + c * c; }
+__device__ __forceinline__ float pdist3(float x0, float x1, float x2, float sx, float y0, float y1, float y2, float sy) {
+  const float xy = fmaf(x2, y2, fmaf(x1, y1, x0 * y0));
+  const float d = (sx - 2.0f * xy) + sy;
+  return d < 0.0f ? 0.0f : d;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

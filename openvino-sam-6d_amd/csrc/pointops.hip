@@ -1,0 +1,310 @@
+// Point-cloud primitives of the PEM matching path for gfx950: farthest-point sampling, index gathers, ball query,
+// grouping.  These are the device side of the reference's `pointnet2._ext` seam (EXT/src/bindings.cpp:11-24) and
+// reproduce the reference's CPU loops bit-for-bit (EXT/src/sampling.cpp:76-118, ball_query.cpp:16-62,
+// group_points.cpp:20-45); the CUDA kernels in EXT/src/*_gpu.cu differ from those loops (no origin skip, other tie
+// order) and are NOT the contract.
+//
+// HBM-bound / latency-bound integer+fp32 work: no MFMA here.  Layout notes per kernel.
+#include "common.h"
+#include "../../include/sam6d_hip.h"
+
+#include <float.h>
+
+// =========================================================================================================
+// Farthest point sampling.
+// One workgroup per cloud (the selection is sequential in j).  Points live in LDS (for the broadcast of the last
+// selected point) and each thread keeps its PPT points + running min-distance in registers.  Per round:
+// PPT distance updates -> thread-local arg-max -> wave64 butterfly on a packed 64-bit key -> one LDS slot per wave
+// -> one barrier -> every thread reduces the NW wave slots.
+//
+// Key packing: d2 >= +0 so its bit pattern is monotone; key = bits(d2) << 32 | ~idx  => max key = max distance,
+// lowest index on ties  == the reference's strict `d2 > best` scan in increasing k (sampling.cpp:105-111).
+// Points inside the origin ball (mag <= 1e-3, compared in double like the reference, sampling.cpp:102-103) never
+// compete and keep temp = FLT_MAX; their key is 0.  If every point is skipped the result is index 0, as in the
+// reference (besti initialised to 0).
+// =========================================================================================================
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restrict__ xyz, int N, int m,
+                                                         int* __restrict__ out) {
+  extern __shared__ float smem[];  // [N*3] points, then wave slots
+  constexpr int NW = THREADS / 64;
+  float* sp = smem;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + ((N * 3 + 3) & ~3));  // [2][NW]
+
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const float* p = xyz + (size_t)b * N * 3;
+  int* o = out + (size_t)b * m;
+
+  for (int i = t; i < N * 3; i += THREADS) sp[i] = p[i];
+  __syncthreads();
+
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  bool live[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * THREADS;
+    if (k < N) {
+      px[i] = sp[k * 3 + 0];
+      py[i] = sp[k * 3 + 1];
+      pz[i] = sp[k * 3 + 2];
+      const float mag = px[i] * px[i] + py[i] * py[i] + pz[i] * pz[i];
+      live[i] = !((double)mag <= 1e-3);
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+      live[i] = false;
+    }
+    td[i] = FLT_MAX;
+  }
+  if (t == 0) o[0] = 0;
+  int last = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = sp[last * 3 + 0], y1 = sp[last * 3 + 1], z1 = sp[last * 3 + 2];
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (live[i]) {
+        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = (td[i] < d) ? td[i] : d;
+        td[i] = d2;
+        const unsigned int k = (unsigned int)(t + i * THREADS);
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(~k);
+        key = kk > key ? kk : key;
+      }
+    }
+    key = wave_max_u64(key);
+    unsigned long long* sl = slots + (j & 1) * NW;
+    if ((t & 63) == 0) sl[t >> 6] = key;
+    __syncthreads();
+    unsigned long long best = sl[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const unsigned long long v = sl[w];
+      best = v > best ? v : best;
+    }
+    last = (best == 0ull) ? 0 : (int)(~(unsigned int)(best & 0xffffffffull));
+    if (t == 0) o[j] = last;
+  }
+}
+
+// Large-N variant (e.g. the 210 000-point template cloud of get_obj_feats, PEM/model/feature_extraction.py:152-158):
+// running min-distances live in a global scratch row (`temp`, the same (B,N) buffer the reference allocates and never
+// uses on CPU, sampling.cpp:192-194); points are re-read from global/L2 each round.  Same selection rule.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fps_big_kernel(const float* __restrict__ xyz, int N, int m,
+                                                         float* __restrict__ temp, int* __restrict__ out) {
+  constexpr int NW = THREADS / 64;
+  __shared__ unsigned long long slots[2][NW];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* p = xyz + (size_t)b * N * 3;
+  float* td = temp + (size_t)b * N;
+  int* o = out + (size_t)b * m;
+  for (int k = t; k < N; k += THREADS) td[k] = FLT_MAX;
+  if (t == 0) o[0] = 0;
+  int last = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = p[last * 3 + 0], y1 = p[last * 3 + 1], z1 = p[last * 3 + 2];
+    unsigned long long key = 0ull;
+    for (int k = t; k < N; k += THREADS) {
+      const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+      const float mag = x2 * x2 + y2 * y2 + z2 * z2;
+      if ((double)mag <= 1e-3) continue;
+      const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float old = td[k];
+      const float d2 = (old < d) ? old : d;
+      td[k] = d2;
+      const unsigned long long kk =
+          ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(~(unsigned int)k);
+      key = kk > key ? kk : key;
+    }
+    key = wave_max_u64(key);
+    if ((t & 63) == 0) slots[j & 1][t >> 6] = key;
+    __syncthreads();
+    unsigned long long best = slots[j & 1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const unsigned long long v = slots[j & 1][w];
+      best = v > best ? v : best;
+    }
+    last = (best == 0ull) ? 0 : (int)(~(unsigned int)(best & 0xffffffffull));
+    if (t == 0) o[j] = last;
+  }
+}
+
+extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int* idx,
+                                             void* stream) {
+  SAM6D_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && m >= 0, "furthest_point_sampling: bad sizes B=%d N=%d m=%d", B, N, m);
+  if (B == 0 || m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)((N * 3 + 3) & ~3) * 4 + 2 * 16 * 8;
+  if (N <= 512 * 4) {
+    hipLaunchKernelGGL((fps_reg_kernel<512, 4>), dim3(B), dim3(512), lds, s, xyz, N, m, idx);
+  } else if (N <= 1024 * 4) {  // 48 KB of LDS points: stays under the 64 KB dynamic-LDS default
+    hipLaunchKernelGGL((fps_reg_kernel<1024, 4>), dim3(B), dim3(1024), lds, s, xyz, N, m, idx);
+  } else {
+    SAM6D_REQUIRE(temp, "furthest_point_sampling: N=%d > 4096 needs the (B,N) float scratch `temp`", N);
+    hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx);
+  }
+  SAM6D_LAUNCH_CHECK("furthest_point_sampling");
+}
+
+// =========================================================================================================
+// gather_points: out[b,c,j] = points[b,c,idx[b,j]], 0 for an out-of-range index (sampling.cpp:23-44).
+// (B,C,N) channel-major layout as the `_ext` seam has it; the pipeline itself uses gather_rows below.
+// =========================================================================================================
+__global__ void gather_points_kernel(const float* __restrict__ points, const int* __restrict__ idx, int C, int N, int M,
+                                     float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int c = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const int a = idx[(size_t)b * M + j];
+  const float* row = points + ((size_t)b * C + c) * N;
+  out[((size_t)b * C + c) * M + j] = (a >= 0 && a < N) ? row[a] : 0.0f;
+}
+
+extern "C" int sam6d_gather_points(const float* points, const int* idx, int B, int C, int N, int M, float* out,
+                                   void* stream) {
+  SAM6D_REQUIRE(points && idx && out, "gather_points: null pointer");
+  SAM6D_REQUIRE(B >= 0 && C >= 0 && N > 0 && M >= 0, "gather_points: bad sizes");
+  SAM6D_REQUIRE(C <= 65535 && B <= 65535, "gather_points: C and B must be <= 65535");
+  if (B == 0 || C == 0 || M == 0) return 0;
+  dim3 grid(cdiv(M, 256), C, B);
+  hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, points, idx, C, N, M, out);
+  SAM6D_LAUNCH_CHECK("gather_points");
+}
+
+// Row gather on the (B,N,C) layout the pipeline keeps its features in: out[b,j,:] = feats[b,idx[b,j]+off,:].
+// One wave per output row, 16-byte lanes.  Out-of-range index -> zeros (same rule as gather_points).
+__global__ void gather_rows_kernel(const float* __restrict__ feats, const int* __restrict__ idx, int N, int M, int C,
+                                   long in_stride_b, long out_stride_b, int idx_off, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= M) return;
+  const int a = idx[(size_t)b * M + j] + idx_off;
+  const bool ok = (a >= 0 && a < N);
+  const float4* src = reinterpret_cast<const float4*>(feats + (size_t)b * in_stride_b + (size_t)(ok ? a : 0) * C);
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)b * out_stride_b + (size_t)j * C);
+  for (int c = (threadIdx.x & 63); c < C / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b,
+                                 long out_stride_b, int idx_off, float* out, void* stream) {
+  SAM6D_REQUIRE(feats && idx && out, "gather_rows: null pointer");
+  SAM6D_REQUIRE(C % 4 == 0, "gather_rows: C must be a multiple of 4 (got %d)", C);
+  if (B == 0 || M == 0) return 0;
+  dim3 grid(cdiv(M, 4), B);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, idx, N, M, C,
+                     in_stride_b, out_stride_b, idx_off, out);
+  SAM6D_LAUNCH_CHECK("gather_rows");
+}
+
+// =========================================================================================================
+// Ball query (ball_query.cpp:16-62): per query, the first `nsample` indices k (increasing) with d2 < r*r; the first
+// hit pre-fills every slot; no hit -> zeros.  d2 in plain fp32, source order, no FMA.
+// One wave per query: 64 candidates per step from an LDS-staged chunk of the cloud, ballot + prefix popcount keep
+// the reference's index order.  QPB queries per block, candidate chunks of CH points (48 KB) so any N works.
+// =========================================================================================================
+#define BQ_CH 4096
+#define BQ_QPB 64
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz, const float* __restrict__ xyz,
+                                                         int N, int M, float radius2, int nsample,
+                                                         int* __restrict__ idx) {
+  __shared__ float sp[BQ_CH * 3];
+  __shared__ int s_cnt[BQ_QPB];
+  __shared__ int s_first[BQ_QPB];
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * BQ_QPB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cx = xyz + (size_t)b * N * 3;
+  const float* cq = new_xyz + (size_t)b * M * 3;
+  int* ci = idx + (size_t)b * M * nsample;
+  if (threadIdx.x < BQ_QPB) {
+    s_cnt[threadIdx.x] = 0;
+    s_first[threadIdx.x] = 0;
+  }
+  for (int base = 0; base < N; base += BQ_CH) {
+    const int cn = min(BQ_CH, N - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cn * 3; i += 256) sp[i] = cx[(size_t)base * 3 + i];
+    __syncthreads();
+    for (int ql = wave; ql < BQ_QPB; ql += 4) {
+      const int q = q0 + ql;
+      if (q >= M) break;
+      int cnt = s_cnt[ql];
+      if (cnt >= nsample) continue;
+      const float qx = cq[q * 3 + 0], qy = cq[q * 3 + 1], qz = cq[q * 3 + 2];
+      int first = s_first[ql];
+      for (int k0 = 0; k0 < cn && cnt < nsample; k0 += 64) {
+        const int k = k0 + lane;
+        bool hit = false;
+        if (k < cn) {
+          const float x = sp[k * 3 + 0], y = sp[k * 3 + 1], z = sp[k * 3 + 2];
+          const float d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+          hit = d2 < radius2;
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          if (cnt == 0) first = base + k0 + (__ffsll((long long)mask) - 1);
+          const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+          if (hit && pos < nsample) ci[(size_t)q * nsample + pos] = base + k;
+          cnt += __popcll(mask);
+        }
+      }
+      if (lane == 0) {
+        s_cnt[ql] = cnt;
+        s_first[ql] = first;
+      }
+    }
+  }
+  __syncthreads();
+  // tail fill: slots [cnt, nsample) hold the first hit (or 0 when the ball is empty)
+  for (int ql = wave; ql < BQ_QPB; ql += 4) {
+    const int q = q0 + ql;
+    if (q >= M) break;
+    const int cnt = min(s_cnt[ql], nsample), first = s_first[ql];
+    for (int l = cnt + lane; l < nsample; l += 64) ci[(size_t)q * nsample + l] = first;
+  }
+}
+
+extern "C" int sam6d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
+                                int* idx, void* stream) {
+  SAM6D_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample > 0, "ball_query: bad sizes");
+  SAM6D_REQUIRE(B <= 65535, "ball_query: B must be <= 65535");
+  if (B == 0 || M == 0) return 0;
+  const float r2 = radius * radius;  // fp32 product, as the reference (ball_query.cpp:20)
+  dim3 grid(cdiv(M, BQ_QPB), B);
+  hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, new_xyz, xyz, N, M, r2, nsample, idx);
+  SAM6D_LAUNCH_CHECK("ball_query");
+}
+
+// =========================================================================================================
+// group_points: out[b,c,j,k] = points[b,c,idx[b,j,k]] (0 when out of range), group_points.cpp:20-45.
+// =========================================================================================================
+__global__ void group_points_kernel(const float* __restrict__ points, const int* __restrict__ idx, int C, int N,
+                                    long MS, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= MS) return;
+  const int a = idx[(size_t)b * MS + e];
+  const bool ok = (a >= 0 && a < N);
+  const float* pb = points + (size_t)b * C * N;
+  float* ob = out + (size_t)b * C * MS;
+  for (int c = 0; c < C; ++c) ob[(size_t)c * MS + e] = ok ? pb[(size_t)c * N + a] : 0.0f;
+}
+
+extern "C" int sam6d_group_points(const float* points, const int* idx, int B, int C, int N, int M, int S, float* out,
+                                  void* stream) {
+  SAM6D_REQUIRE(points && idx && out, "group_points: null pointer");
+  SAM6D_REQUIRE(B >= 0 && C >= 0 && N > 0 && M >= 0 && S >= 0, "group_points: bad sizes");
+  SAM6D_REQUIRE(B <= 65535, "group_points: B must be <= 65535");
+  if (B == 0 || C == 0 || M == 0 || S == 0) return 0;
+  const long MS = (long)M * S;
+  dim3 grid((unsigned)((MS + 255) / 256), B);
+  hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, points, idx, C, N, MS, out);
+  SAM6D_LAUNCH_CHECK("group_points");
+}

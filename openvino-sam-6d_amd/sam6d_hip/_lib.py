@@ -1,0 +1,54 @@
+"""ctypes binding of libsam6d_hip.so (the C ABI declared in include/sam6d_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises, and every op
+raises RuntimeError on a non-zero return code (message from sam6d_last_error()).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsam6d_hip.so")
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_p = ctypes.c_void_p
+
+# name -> argtypes (all return int).  Must mirror include/sam6d_hip.h exactly; tests/test_abi.py parses the header
+# and checks that every declared symbol is exported and listed here.
+SIGNATURES = {
+    "sam6d_furthest_point_sampling": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_gather_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_ball_query": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
+    "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsam6d_hip.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C openvino-sam-6d_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sam6d_last_error.restype = ctypes.c_char_p
+    lib.sam6d_last_error.argtypes = []
+    lib.sam6d_abi_version.restype = c_i
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = args
+        fn.restype = c_i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, lib.sam6d_last_error().decode()))

@@ -1,0 +1,145 @@
+"""GPU parity of the `pointnet2._ext` seam: HIP kernels vs golden vectors captured from the reference's own
+compiled CPU loops (tests/golden/pointops.npz) and vs the C oracle on fresh seeded inputs.  Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(t):
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import pointnet2._ext as e
+    return e
+
+
+def test_fps_golden(dev, ext):
+    g = golden("pointops")
+    xyz = torch.from_numpy(g["fps_xyz"]).to(dev)
+    idx = ext.furthest_point_sampling(xyz, 196)
+    assert idx.dtype == torch.int32 and idx.shape == (2, 196)
+    assert np.array_equal(idx.cpu().numpy(), g["fps_idx"])
+
+
+def test_fps_reference_test_shape(dev, ext):
+    g = golden("pointops")
+    rs = np.random.RandomState(324)  # ov_test_furthest_point_sampling_1input.py seeds/shapes
+    big = torch.from_numpy(rs.randn(1, 21000, 3).astype(np.float32)).to(dev)
+    idx = ext.furthest_point_sampling(big, 2048)
+    assert np.array_equal(idx.cpu().numpy(), g["fps_big_idx"])
+
+
+@pytest.mark.parametrize("B,N,m", [(3, 2048, 196), (2, 1000, 64), (1, 4096, 300), (2, 5000, 128), (1, 64, 64), (2, 7, 3)])
+def test_fps_vs_oracle(dev, ext, B, N, m):
+    from oracle import pointops as P
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    xyz = torch.rand(B, N, 3, generator=g) - 0.5
+    xyz[0, ::5] *= 0.03  # origin-ball skip branch
+    if B > 1:
+        xyz[1] += torch.tensor([0.0, 0.0, 8.0])
+    want = P.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(xyz.to(dev), m)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_fps_all_points_in_origin_ball(dev, ext):
+    from oracle import pointops as P
+    xyz = torch.full((1, 256, 3), 0.001)
+    assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), 8).cpu(), P.furthest_point_sampling(xyz, 8))
+
+
+def test_fps_duplicate_points_tie_break(dev, ext):
+    from oracle import pointops as P
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(1, 64, 3, generator=g) + 1.0
+    xyz = base.repeat(1, 8, 1).contiguous()  # every point 8x: exact ties, lowest index must win
+    assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), 40).cpu(), P.furthest_point_sampling(xyz, 40))
+
+
+def test_gather_golden(dev, ext):
+    g = golden("pointops")
+    gen = torch.Generator().manual_seed(11)
+    _ = torch.rand(2, 2048, 3, generator=gen)  # same stream position as oracle/gen_golden.py:fx_pointops
+    feats = torch.randn(16, 128, 256, generator=gen)
+    idx = torch.from_numpy(g["gather_idx"])
+    out = ext.gather_points(feats.to(dev), idx.to(dev))
+    assert _sha(out) == str(g["gather_out_sha"])
+    assert np.array_equal(out[0].cpu().numpy(), g["gather_out_b0"])
+    assert out[0, :, 0].abs().max() == 0 and out[0, :, 1].abs().max() == 0  # idx -1 and 256 -> 0
+
+
+def test_ball_query_golden(dev, ext):
+    g = golden("pointops")
+    pts = torch.from_numpy(g["bq_pts"]).to(dev)
+    q = (pts + 0.00000001).contiguous()
+    i1 = ext.ball_query(q, pts, 0.1, 32)
+    i2 = ext.ball_query(q, pts, 0.2, 64)
+    assert np.array_equal(i1.cpu().numpy(), g["bq_r1"].astype(np.int32))
+    assert np.array_equal(i2.cpu().numpy(), g["bq_r2"].astype(np.int32))
+    grp = ext.group_points(pts.transpose(1, 2).contiguous(), i1)
+    assert _sha(grp) == str(g["group_hot_sha"])
+
+
+def test_ball_query_reference_test_shape(dev, ext):
+    g = golden("pointops")
+    rs = np.random.RandomState(324)
+    _ = rs.randn(1, 21000, 3)
+    nx = torch.from_numpy(rs.randn(1, 1024, 3).astype(np.float32)).to(dev)
+    xx = torch.from_numpy(rs.randn(1, 256, 3).astype(np.float32)).to(dev)
+    got = ext.ball_query(nx, xx, 0.1, 64)
+    assert np.array_equal(got.cpu().numpy(), g["bq_ref_test"].astype(np.int32))
+
+
+@pytest.mark.parametrize("B,N,M,r,ns", [(2, 2048, 2048, 0.2, 64), (1, 5000, 300, 0.15, 16), (3, 100, 37, 0.5, 8),
+                                         (1, 9000, 65, 0.05, 32)])
+def test_ball_query_group_vs_oracle(dev, ext, B, N, M, r, ns):
+    from oracle import pointops as P
+    g = torch.Generator().manual_seed(N + M)
+    xyz = torch.rand(B, N, 3, generator=g) - 0.5
+    new = (torch.rand(B, M, 3, generator=g) - 0.5) * 1.3  # some queries have empty balls
+    want = P.ball_query(new, xyz, r, ns)
+    got = ext.ball_query(new.to(dev), xyz.to(dev), r, ns)
+    assert torch.equal(got.cpu(), want)
+    feats = torch.randn(B, 5, N, generator=g)
+    assert torch.equal(ext.group_points(feats.to(dev), got).cpu(), P.group_points(feats, want))
+
+
+def test_group_golden(dev, ext):
+    g = golden("pointops")
+    gen = torch.Generator().manual_seed(11)
+    _ = torch.rand(2, 2048, 3, generator=gen)
+    _ = torch.randn(16, 128, 256, generator=gen)
+    _ = torch.randint(0, 256, (16, 64), generator=gen, dtype=torch.int32)
+    _ = torch.rand(2, 2048, 3, generator=gen)
+    gf = torch.randn(7, 3, 2048, generator=gen)
+    gi = torch.randint(0, 2048, (7, 2048, 32), generator=gen, dtype=torch.int32)
+    out = ext.group_points(gf.to(dev), gi.to(dev))
+    assert _sha(out) == str(g["group_out_sha"])
+
+
+def test_gather_rows(dev):
+    from sam6d_hip import ops
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn(3, 300, 256, generator=g)
+    idx = torch.randint(0, 300, (3, 50), generator=g, dtype=torch.int32)
+    got = ops.gather_rows(f.to(dev), idx.to(dev))
+    want = torch.gather(f, 1, idx.long().unsqueeze(2).expand(3, 50, 256))
+    assert torch.equal(got.cpu(), want)
+
+
+def test_error_contract(dev, ext):
+    x = torch.zeros(1, 16, 3, device=dev)
+    with pytest.raises(RuntimeError):
+        ext.ball_query(x.transpose(1, 2), x, 0.1, 4)  # non-contiguous
+    with pytest.raises(RuntimeError):
+        ext.gather_points(x, torch.zeros(1, 4, dtype=torch.int64, device=dev))  # idx must be int32
+    with pytest.raises(NotImplementedError):
+        ext.three_nn(x, x)
