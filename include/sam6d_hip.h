@@ -55,6 +55,97 @@ int sam6d_group_points(const float* points, const int* idx, int B, int C, int N,
 int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b,
                       long out_stride_b, int idx_off, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * B2: building blocks of the PEM Python modules (CoarsePointMatching / FinePointMatching / GeometricTransformer /
+ * model_utils).  The reference runs these as torch ops; here each is one or a few HIP launches.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* C = act(((A . W^T) / divisor) * colscale + bias) + residual  on the fp32 matrix cores.
+ * replaces nn.Linear / 1x1-conv call sites (PEM/model/transformer.py:127-129,186-188,390-393,548-550;
+ * PEM/model/coarse_point_matching.py:35-38) and the similarity contraction (PEM/utils/model_utils.py:144-150).
+ * A (M,K) lda; W (N,K) ldw; C (M,N) ldc; residual (M,N) ldr or NULL; bias/colscale (N) or NULL; act 0 none / 1 ReLU;
+ * `batch` independent problems with strides sA/sW/sC/sR (floats).  divisor = 1 disables the division. */
+int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
+                  float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
+                  long sC, long sR, float divisor, int act, void* stream);
+
+/* nn.LayerNorm(256) over `rows` rows (PEM/model/transformer.py:158,189,436,597).  eps as in torch (1e-5). */
+int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, float* y, long rows, long ldx, long ldy,
+                       float eps, void* stream);
+
+/* replaces GeometricStructureEmbedding.forward (PEM/model/transformer.py:343-363; indices :306-341; sinusoid :259-285).
+ * points (B,n,3) (bg point already prepended) -> out (B,n,n,256).  Workspaces: knn_ws (B*n*3) i32, idx_ws (B*n*n*4) f32. */
+int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd, const float* bd,
+                        const float* Wa, const float* ba, float sigma_d, float factor_a, int angle_k, int hidden,
+                        int* knn_ws, float* idx_ws, float* out, void* stream);
+
+/* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
+ * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).
+ * RPE form: qp (B,n,4,256) = per-head query folded through proj_p, E (B,n,m,256); pass both NULL for the plain form. */
+int sam6d_attention(const float* q, const float* k, const float* v, const float* qp, const float* E, float* out, int B,
+                    int n, int m, long ldq, long ldk, long ldv, long ldo, long sq, long sk, long sv, long so,
+                    void* stream);
+
+/* LinearAttention.forward pieces (PEM/model/transformer.py:546-578, kv path :569-572). */
+int sam6d_linattn_focus_k(float* k, const float* scale, long rows, long ld, void* stream);
+int sam6d_linattn_kv(const float* k, const float* v, int B, int J, long ldk, long ldv, long sk, long sv, float* kvT,
+                     float* ksum, void* stream);
+int sam6d_linattn_focus_q(float* q, const float* scale, const float* ksum, int B, long rows_per_b, long ld,
+                          void* stream);
+
+/* PositionalEncoding helpers (PEM/model/fine_point_matching.py:113-144; QueryAndGroup
+ * PEM/model/pointnet2/pointnet2_utils.py:326-403): 6-channel grouped rows, and the max over each ball. */
+int sam6d_pe_group_rows(const float* pts, const int* idx, int B, int N, int S, float* rows, void* stream);
+int sam6d_group_max(const float* x, long groups, int S, int C, long ldo, int off, float* out, void* stream);
+
+/* y = (x - t) @ R per batch element (PEM/model/fine_point_matching.py:45). */
+int sam6d_rigid_inverse(const float* x, const float* R, const float* t, int B, int N, float* y, void* stream);
+/* strided row-block copy (the torch.cat call sites that add the bg token, PEM/model/coarse_point_matching.py:36-38). */
+int sam6d_put_rows(const float* src, long s_src_b, long ld_src, float* dst, long s_dst_b, long ld_dst, int B, int rows,
+                   int C, void* stream);
+/* cat([bg_point(100,100,100), pts]) (PEM/model/pose_estimation_model.py:30-34). */
+int sam6d_prepend_bg_point(const float* pts, int B, int n, float* out, void* stream);
+/* y = x + s (new_xyz = pts + 1e-8, PEM/model/fine_point_matching.py:117) and a flat device copy of n floats
+ * (batch stacking: the .repeat / torch.cat call sites PEM/run_inference_custom_pytorch.py:445-446). */
+int sam6d_add_scalar(const float* x, float s, long n, float* y, void* stream);
+int sam6d_copy_f32(const float* src, float* dst, long n, void* stream);
+/* F.normalize(dim=-1) on 256-wide rows (PEM/utils/model_utils.py:141-142). */
+int sam6d_l2norm256(const float* x, float* y, long rows, long ldx, long ldy, void* stream);
+
+/* Soft assignment statistics and labels (PEM/utils/model_utils.py:229-235, 320-324): att (B,R,C);
+ * rmax/rsum (B,R), cmax/csum (B,C), label1 (B,R-1) i32, label2 (B,C-1) i32. */
+int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
+                      int* label1, int* label2, void* stream);
+/* Sampling weights (S[1:,1:] * w1 * w2) ** 1.5 -> (B,(R-1)*(C-1)), w1 (B,R-1) (PEM/utils/model_utils.py:234-238). */
+int sam6d_coarse_weights(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
+                         const float* csum, const int* label1, const int* label2, float* weights, float* w1,
+                         void* stream);
+/* replaces cumsum + weighted_sampling_onnx_compatible (PEM/utils/model_utils.py:241-250, 277-305): `rand` (B,ns) are
+ * the uniforms the reference draws with torch.rand (:292); idx (B,ns) i32; cum_ws (B,L) f32 scratch. */
+int sam6d_weighted_sample(const float* weights, const float* rand, int B, int L, int ns, float* cum_ws, int* idx,
+                          void* stream);
+/* 3-point Procrustes per hypothesis + residual (PEM/utils/model_utils.py:244-257): idx (B,3*nh) -> Rs (B,nh,9),
+ * ts (B,nh,3), dis (B,nh). */
+int sam6d_coarse_hypotheses(const int* idx, const float* pts1, const float* pts2, int B, int N1, int N2, int nh,
+                            float* Rs, float* ts, float* dis, void* stream);
+/* torch.topk(k, largest=False) indices, ascending (PEM/utils/model_utils.py:258). */
+int sam6d_select_smallest(const float* dis, int B, int n, int k, int* sel, void* stream);
+/* Hypothesis scoring + argmax (PEM/utils/model_utils.py:261-270); model (B,P,3) raw, radius (B). */
+int sam6d_score_select_hypotheses(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,
+                                  const float* model, const float* radius, int B, int N1, int P, int nh, int k,
+                                  float* scores, float* R, float* t, int* best, void* stream);
+/* Fine soft-assignment reduction (PEM/utils/model_utils.py:325-331): pred (B,R-1,3), weight (B,R-1). */
+int sam6d_fine_assign(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
+                      const float* csum, const int* label1, const int* label2, const float* pts2, float* pred,
+                      float* weight, void* stream);
+/* replaces weighted_procrustes (PEM/utils/model_utils.py:343-436; CustomSVD/CustomDet :469-526); weights may be NULL. */
+int sam6d_weighted_procrustes(const float* src, const float* ref, const float* weights, int B, int N,
+                              float weight_thresh, float eps, float* R, float* t, void* stream);
+/* Fine pose score and translation rescale (PEM/utils/model_utils.py:331-339; PEM/model/fine_point_matching.py:78);
+ * t is scaled in place by (radius + 1e-6); cnt_ws (2*B) f32 scratch. */
+int sam6d_fine_score(const float* pts1, const float* R, float* t, const float* model, const float* radius,
+                     const int* label1, int B, int N, int P, float dis_thres, float* cnt_ws, float* score, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

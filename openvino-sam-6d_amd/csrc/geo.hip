@@ -1,0 +1,206 @@
+// GeometricStructureEmbedding for gfx950 (PEM/model/transformer.py:288-363, SinusoidalPositionalEmbedding :259-285).
+//
+// Three launches per call, no (B,n,n,3,256) intermediate ever reaches HBM (the reference materialises 3.8 GB of it at
+// B=32):
+//   1. geo_knn_kernel     per point: squared distances in the torch-CPU bit recipe (common.h pdist3), sqrt, the k=3
+//                         nearest neighbours = entries 1..3 of the 4 smallest by (value, index)  (:318-321)
+//   2. geo_index_kernel   per pair (i,j): d_idx = sqrt(pd)/sigma_d and the k angular indices
+//                         atan2(clamp(|ref x anc|,1e-8), clamp(ref.anc,-1,1)) * factor_a            (:322-341)
+//   3. geo_embed_kernel   per 32 pairs: rows {d, a0, a1, a2} x 256 sinusoid features are GENERATED in LDS
+//                         (sin/cos of idx*omega_i, interleaved, :276-283) and contracted with proj_d / proj_a on the
+//                         fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32); epilogue
+//                         out = (acc_d + b_d) + (max_k acc_a + b_a) entirely in registers (:350-361).
+#include "common.h"
+#include "../../include/sam6d_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------- 1. kNN
+// one wave per (b,i); n <= 256 (4 candidates per lane).  4 rounds of wave arg-min on (bits(dist), index).
+__global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ pts, int n, int k, int* __restrict__ knn,
+                                                      long total) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= total) return;
+  const int lane = threadIdx.x & 63;
+  const long b = w / n;
+  const int i = (int)(w % n);
+  const float* p = pts + b * n * 3;
+  const float x0 = p[i * 3], x1 = p[i * 3 + 1], x2 = p[i * 3 + 2];
+  const float sx = sqnorm3(x0, x1, x2);
+  unsigned long long key[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = lane + 64 * u;
+    if (j < n) {
+      const float y0 = p[j * 3], y1 = p[j * 3 + 1], y2 = p[j * 3 + 2];
+      const float d = sqrtf(pdist3(x0, x1, x2, sx, y0, y1, y2, sqnorm3(y0, y1, y2)));
+      key[u] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+    } else {
+      key[u] = ~0ull;
+    }
+  }
+  for (int r = 0; r <= k; ++r) {
+    unsigned long long m = key[0];
+#pragma unroll
+    for (int u = 1; u < 4; ++u) m = key[u] < m ? key[u] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long v = __shfl_xor(m, o, 64);
+      m = v < m ? v : m;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (key[u] == m) key[u] = ~0ull;  // remove the winner (keys are unique: the index is part of the key)
+    if (r >= 1 && lane == 0) knn[w * k + (r - 1)] = (int)(m & 0xffffffffull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 2. indices
+// idx4[(b,i,j)] = {d_idx, a_idx[0..2]}  (k == 3)
+__global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
+                                                        float sigma_d, float factor_a, float4* __restrict__ idx4,
+                                                        long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e % n);
+  const long bi = e / n;
+  const int i = (int)(bi % n);
+  const long b = bi / n;
+  const float* p = pts + b * n * 3;
+  const float x0 = p[i * 3], x1 = p[i * 3 + 1], x2 = p[i * 3 + 2];
+  const float y0 = p[j * 3], y1 = p[j * 3 + 1], y2 = p[j * 3 + 2];
+  const float pd = pdist3(x0, x1, x2, sqnorm3(x0, x1, x2), y0, y1, y2, sqnorm3(y0, y1, y2));
+  float out[4];
+  out[0] = sqrtf(pd) / sigma_d;
+  const float a0 = y0 - x0, a1 = y1 - x1, a2 = y2 - x2;  // anchor vector  p_j - p_i
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int q = knn[bi * 3 + r];
+    const float r0 = p[q * 3] - x0, r1 = p[q * 3 + 1] - x1, r2 = p[q * 3 + 2] - x2;  // reference vector
+    const float c0 = r1 * a2 - r2 * a1, c1 = r2 * a0 - r0 * a2, c2 = r0 * a1 - r1 * a0;
+    float s = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    float c = (r0 * a0 + r1 * a1) + r2 * a2;
+    s = fmaxf(s, 1e-8f);
+    c = fminf(fmaxf(c, -1.0f + 1e-8f), 1.0f - 1e-8f);  // == clamp(-1, 1) in fp32
+    out[r + 1] = atan2f(s, c) * factor_a;
+  }
+  idx4[e] = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// ---------------------------------------------------------------------------------------------- 3. embedding
+// 256 threads = 4 waves; block = 32 pairs = 128 generated rows (group g: 0 -> d, 1..3 -> a_k); wave w owns output
+// columns [64w, 64w+64).  Per 16-wide K chunk: A tile [128][17] generated, B tile {W_d, W_a}[256][17] staged.
+#define GE_P 32
+#define GE_BK 16
+#define GE_LD 17
+__global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
+                                                           const float* __restrict__ Wd, const float* __restrict__ bd,
+                                                           const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                           float* __restrict__ out, long total) {
+  __shared__ float As[4 * GE_P * GE_LD];       // 128 rows
+  __shared__ float Bs[2 * 256 * GE_LD];        // [mat][col][k]
+  __shared__ float xs[4 * GE_P];               // embedding index of each generated row
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long p0 = (long)blockIdx.x * GE_P;
+  if (t < GE_P) {
+    const long e = min(p0 + t, total - 1);
+    const float4 v = idx4[e];
+    xs[0 * GE_P + t] = v.x;
+    xs[1 * GE_P + t] = v.y;
+    xs[2 * GE_P + t] = v.z;
+    xs[3 * GE_P + t] = v.w;
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.f;
+  __syncthreads();
+  const int grow = t & 127, gf0 = (t >> 7) * 4;  // A generation: row, first of 4 frequencies of this chunk
+  const float xrow = xs[grow];
+  const int fr = lane & 31, fk = lane >> 5;
+  const int wn = wave * 64;
+  for (int k0 = 0; k0 < 256; k0 += GE_BK) {
+    // stage B: 2 mats x 256 cols x 16 k = 2048 float4, 8 per thread
+    float4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int id = t + 256 * u;
+      const int mat = id >> 10, col = (id >> 2) & 255, k4 = (id & 3) * 4;
+      const float* src = (mat ? Wa : Wd) + (size_t)col * 256 + k0 + k4;
+      wv[u] = *reinterpret_cast<const float4*>(src);
+    }
+    float sv[4], cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float om = xrow * div_term[(k0 >> 1) + gf0 + u];
+      sincosf(om, &sv[u], &cv[u]);
+    }
+    __syncthreads();  // previous chunk consumed
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int id = t + 256 * u;
+      const int mat = id >> 10, col = (id >> 2) & 255, k4 = (id & 3) * 4;
+      float* dst = Bs + (mat * 256 + col) * GE_LD + k4;
+      dst[0] = wv[u].x; dst[1] = wv[u].y; dst[2] = wv[u].z; dst[3] = wv[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      As[grow * GE_LD + 2 * (gf0 + u)] = sv[u];
+      As[grow * GE_LD + 2 * (gf0 + u) + 1] = cv[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GE_BK; kk += 2) {
+      const float bd0 = Bs[(0 * 256 + wn + fr) * GE_LD + kk + fk];
+      const float bd1 = Bs[(0 * 256 + wn + 32 + fr) * GE_LD + kk + fk];
+      const float ba0 = Bs[(1 * 256 + wn + fr) * GE_LD + kk + fk];
+      const float ba1 = Bs[(1 * 256 + wn + 32 + fr) * GE_LD + kk + fk];
+      const float a0 = As[(0 * GE_P + fr) * GE_LD + kk + fk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bd0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bd1, acc[0][1], 0, 0, 0);
+#pragma unroll
+      for (int g = 1; g < 4; ++g) {
+        const float ag = As[(g * GE_P + fr) * GE_LD + kk + fk];
+        acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, ba0, acc[g][0], 0, 0, 0);
+        acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, ba1, acc[g][1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn + j * 32 + fr;
+    const float vbd = bd[col], vba = ba[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long e = p0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (e < total) {
+        const float d = acc[0][j][r] + vbd;
+        const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) + vba;
+        out[e * 256 + col] = d + a;
+      }
+    }
+  }
+}
+
+extern "C" int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd,
+                                   const float* bd, const float* Wa, const float* ba, float sigma_d, float factor_a,
+                                   int angle_k, int hidden, int* knn_ws, float* idx_ws, float* out, void* stream) {
+  SAM6D_REQUIRE(points && div_term && Wd && bd && Wa && ba && knn_ws && idx_ws && out, "geo_embedding: null pointer");
+  SAM6D_REQUIRE(angle_k == 3 && hidden == 256, "geo_embedding: only angle_k=3, hidden_dim=256 (PEM/config/base.yaml:26-31)");
+  SAM6D_REQUIRE(B >= 0 && n >= 4 && n <= 256, "geo_embedding: need 4 <= n <= 256 (got %d)", n);
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embedding: idx_ws/weights must be 16-byte aligned");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)B * n, pairs = rows * n;
+  hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, points, n, angle_k, knn_ws, rows);
+  SAM6D_LAUNCH_CHECK_CONT("geo_embedding(knn)");
+  hipLaunchKernelGGL(geo_index_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, points, knn_ws, n, sigma_d,
+                     factor_a, reinterpret_cast<float4*>(idx_ws), pairs);
+  SAM6D_LAUNCH_CHECK_CONT("geo_embedding(indices)");
+  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs);
+  SAM6D_LAUNCH_CHECK("geo_embedding");
+}

@@ -178,7 +178,7 @@ extern "C" int sam6d_gather_points(const float* points, const int* idx, int B, i
 }
 
 // Row gather on the (B,N,C) layout the pipeline keeps its features in: out[b,j,:] = feats[b,idx[b,j]+off,:].
-// One wave per output row, 16-byte lanes.  Out-of-range index -> zeros (same rule as gather_points).
+// One wave per output row, 16-byte lanes when C % 4 == 0.  Out-of-range index -> zeros (same rule as gather_points).
 __global__ void gather_rows_kernel(const float* __restrict__ feats, const int* __restrict__ idx, int N, int M, int C,
                                    long in_stride_b, long out_stride_b, int idx_off, float* __restrict__ out) {
   const int b = blockIdx.y;
@@ -186,15 +186,23 @@ __global__ void gather_rows_kernel(const float* __restrict__ feats, const int* _
   if (j >= M) return;
   const int a = idx[(size_t)b * M + j] + idx_off;
   const bool ok = (a >= 0 && a < N);
-  const float4* src = reinterpret_cast<const float4*>(feats + (size_t)b * in_stride_b + (size_t)(ok ? a : 0) * C);
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)b * out_stride_b + (size_t)j * C);
-  for (int c = (threadIdx.x & 63); c < C / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* srow = feats + (size_t)b * in_stride_b + (size_t)(ok ? a : 0) * C;
+  float* drow = out + (size_t)b * out_stride_b + (size_t)j * C;
+  if ((C & 3) == 0) {
+    const float4* src = reinterpret_cast<const float4*>(srow);
+    float4* dst = reinterpret_cast<float4*>(drow);
+    for (int c = (threadIdx.x & 63); c < C / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int c = (threadIdx.x & 63); c < C; c += 64) drow[c] = ok ? srow[c] : 0.f;
+  }
 }
 
 extern "C" int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b,
                                  long out_stride_b, int idx_off, float* out, void* stream) {
   SAM6D_REQUIRE(feats && idx && out, "gather_rows: null pointer");
-  SAM6D_REQUIRE(C % 4 == 0, "gather_rows: C must be a multiple of 4 (got %d)", C);
+  SAM6D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0 && B <= 65535, "gather_rows: bad sizes");
+  SAM6D_REQUIRE((C & 3) != 0 || (((in_stride_b | out_stride_b) & 3) == 0 && (((size_t)feats | (size_t)out) & 15) == 0),
+                "gather_rows: 16-byte alignment required when C %% 4 == 0");
   if (B == 0 || M == 0) return 0;
   dim3 grid(cdiv(M, 4), B);
   hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, idx, N, M, C,

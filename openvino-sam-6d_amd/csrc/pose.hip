@@ -1,0 +1,665 @@
+// Pose solvers of the matching path for gfx950: soft assignment, weighted hypothesis sampling, batched 3-point and
+// N-point weighted Procrustes (3x3 SVD), hypothesis selection / scoring.
+//   compute_coarse_Rt      PEM/utils/model_utils.py:204-275  (+ weighted_sampling_onnx_compatible :277-305)
+//   compute_fine_Rt        PEM/utils/model_utils.py:308-341
+//   weighted_procrustes    PEM/utils/model_utils.py:343-436  (torch.svd / torch.det :469-481, 513-526)
+// HBM/latency-bound vector work: coalesced row passes, wave butterflies, LDS-staged point sets; no MFMA.
+#include "common.h"
+#include "../../include/sam6d_hip.h"
+
+#include <math.h>
+
+// =========================================================================================================
+// Soft assignment  S = softmax(att, dim=2) * softmax(att, dim=1)   (model_utils.py:229-233, 320-324)
+// att (B, R, C), row 0 / column 0 = background token.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void sa_row_stats_kernel(const float* __restrict__ att, int C, long rows,
+                                                           float* __restrict__ rmax, float* __restrict__ rsum) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* a = att + row * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, a[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(a[c] - mx);
+  s = wave_sum(s);
+  if (lane == 0) {
+    rmax[row] = mx;
+    rsum[row] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void sa_col_stats_kernel(const float* __restrict__ att, int R, int C,
+                                                           float* __restrict__ cmax, float* __restrict__ csum) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* a = att + (size_t)b * R * C + c;
+  float mx = -INFINITY;
+  for (int r = 0; r < R; ++r) mx = fmaxf(mx, a[(size_t)r * C]);
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += expf(a[(size_t)r * C] - mx);
+  cmax[(size_t)b * C + c] = mx;
+  csum[(size_t)b * C + c] = s;
+}
+
+__device__ __forceinline__ float sa_value(float a, float rm, float rs, float cm, float cs) {
+  return (expf(a - rm) / rs) * (expf(a - cm) / cs);
+}
+
+// label1[b, r-1] = argmax_c S[b, r, c] (first maximum), r = 1..R-1  -- one wave per row
+__global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restrict__ att, int R, int C, long rows,
+                                                            const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                            const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                            int* __restrict__ label1) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*(R-1)
+  if (w >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long b = w / (R - 1);
+  const int r = (int)(w % (R - 1)) + 1;
+  const float* a = att + ((size_t)b * R + r) * C;
+  const float rm = rmax[b * R + r], rs = rsum[b * R + r];
+  const float* cm = cmax + b * C;
+  const float* cs = csum + b * C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = sa_value(a[c], rm, rs, cm[c], cs[c]);
+    if (v > best) {
+      best = v;
+      bi = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) label1[w] = (bi == 0x7fffffff) ? 0 : bi;
+}
+
+// label2[b, c-1] = argmax_r S[b, r, c] (first maximum), c = 1..C-1  -- one thread per column
+__global__ __launch_bounds__(256) void sa_col_labels_kernel(const float* __restrict__ att, int R, int C,
+                                                            const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                            const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                            int* __restrict__ label2) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x + 1;
+  if (c >= C) return;
+  const float* a = att + (size_t)b * R * C + c;
+  const float cm = cmax[(size_t)b * C + c], cs = csum[(size_t)b * C + c];
+  const float* rm = rmax + (size_t)b * R;
+  const float* rs = rsum + (size_t)b * R;
+  float best = -INFINITY;
+  int bi = 0;
+  for (int r = 0; r < R; ++r) {
+    const float v = sa_value(a[(size_t)r * C], rm[r], rs[r], cm, cs);
+    if (v > best) {
+      best = v;
+      bi = r;
+    }
+  }
+  label2[(size_t)b * (C - 1) + (c - 1)] = bi;
+}
+
+extern "C" int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
+                                 int* label1, int* label2, void* stream) {
+  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2, "soft_assign: null pointer");
+  SAM6D_REQUIRE(B >= 0 && R >= 2 && C >= 2 && B <= 65535, "soft_assign: bad sizes");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)B * R;
+  hipLaunchKernelGGL(sa_row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, att, C, rows, rmax, rsum);
+  hipLaunchKernelGGL(sa_col_stats_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, att, R, C, cmax, csum);
+  const long lrows = (long)B * (R - 1);
+  hipLaunchKernelGGL(sa_row_labels_kernel, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
+                     cmax, csum, label1);
+  hipLaunchKernelGGL(sa_col_labels_kernel, dim3(cdiv(C - 1, 256), B), dim3(256), 0, s, att, R, C, rmax, rsum, cmax, csum,
+                     label2);
+  SAM6D_LAUNCH_CHECK("soft_assign");
+}
+
+// coarse: weights[b, (r-1)*(C-1) + (c-1)] = (S * [label1>0] * [label2>0]) ^ 1.5 ; w1[b, r-1] = [label1 > 0]
+__global__ __launch_bounds__(256) void coarse_weights_kernel(const float* __restrict__ att, int R, int C,
+                                                             const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                             const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                             const int* __restrict__ label1, const int* __restrict__ label2,
+                                                             float* __restrict__ weights, float* __restrict__ w1, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int n2 = C - 1, n1 = R - 1;
+  const int c = (int)(e % n2) + 1;
+  const long br = e / n2;
+  const int r = (int)(br % n1) + 1;
+  const long b = br / n1;
+  const float a = att[((size_t)b * R + r) * C + c];
+  float v = sa_value(a, rmax[b * R + r], rsum[b * R + r], cmax[b * C + c], csum[b * C + c]);
+  const float f1 = label1[b * n1 + (r - 1)] > 0 ? 1.f : 0.f;
+  const float f2 = label2[b * n2 + (c - 1)] > 0 ? 1.f : 0.f;
+  v = (v * f1) * f2;
+  weights[e] = powf(v, 1.5f);
+  if (c == 1) w1[b * n1 + (r - 1)] = f1;
+}
+
+extern "C" int sam6d_coarse_weights(const float* att, int B, int R, int C, const float* rmax, const float* rsum,
+                                    const float* cmax, const float* csum, const int* label1, const int* label2,
+                                    float* weights, float* w1, void* stream) {
+  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && weights && w1, "coarse_weights: null pointer");
+  const long total = (long)B * (R - 1) * (C - 1);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(coarse_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, att, R,
+                     C, rmax, rsum, cmax, csum, label1, label2, weights, w1, total);
+  SAM6D_LAUNCH_CHECK("coarse_weights");
+}
+
+// =========================================================================================================
+// Weighted sampling: cum = cumsum(w) with a DOUBLE accumulator rounded to float per element (torch CPU cumsum,
+// SURVEY 8c n3); cum /= (cum[-1] + 1e-8); idx = first i with cum[i] >= u, 0 if none (model_utils.py:241-243,277-305).
+// One workgroup per row: each thread scans a contiguous chunk, chunk totals are scanned in LDS (double).
+// =========================================================================================================
+__global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restrict__ w, int L, float* __restrict__ cum) {
+  __shared__ double part[1024];
+  __shared__ float s_total;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* x = w + (size_t)b * L;
+  float* o = cum + (size_t)b * L;
+  const int chunk = (L + 1023) / 1024;
+  const int i0 = t * chunk, i1 = min(L, i0 + chunk);
+  double acc = 0.0;
+  for (int i = i0; i < i1; ++i) acc += (double)x[i];
+  part[t] = acc;
+  __syncthreads();
+  for (int o2 = 1; o2 < 1024; o2 <<= 1) {  // inclusive Hillis-Steele scan
+    const double v = (t >= o2) ? part[t - o2] : 0.0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  double run = (t == 0) ? 0.0 : part[t - 1];
+  for (int i = i0; i < i1; ++i) {
+    run += (double)x[i];
+    o[i] = (float)run;
+  }
+  if (i0 < L && i1 == L) s_total = (float)run;
+  __syncthreads();
+  const float den = s_total + 1e-8f;
+  for (int i = i0; i < i1; ++i) o[i] = o[i] / den;
+}
+
+__global__ __launch_bounds__(256) void sample_first_ge_kernel(const float* __restrict__ cum, const float* __restrict__ u, int L,
+                                                              int ns, long total, int* __restrict__ idx) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / ns;
+  const float* c = cum + b * L;
+  const float v = u[e];
+  int lo = 0, hi = L;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (c[mid] >= v) hi = mid; else lo = mid + 1;
+  }
+  idx[e] = (lo == L) ? 0 : lo;
+}
+
+extern "C" int sam6d_weighted_sample(const float* weights, const float* rand, int B, int L, int ns, float* cum_ws, int* idx,
+                                     void* stream) {
+  SAM6D_REQUIRE(weights && rand && cum_ws && idx && B >= 0 && L > 0 && ns >= 0, "weighted_sample: bad arguments");
+  if (B == 0 || ns == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(cumsum_norm_kernel, dim3(B), dim3(1024), 0, s, weights, L, cum_ws);
+  const long total = (long)B * ns;
+  hipLaunchKernelGGL(sample_first_ge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cum_ws, rand, L, ns, total,
+                     idx);
+  SAM6D_LAUNCH_CHECK("weighted_sample");
+}
+
+// =========================================================================================================
+// 3x3 rotation from the correlation matrix H = sum src_c^T (w ref_c):  R = V diag(1,1,sign det(V U^T)) U^T.
+// Written as R = v1 u1^T + v2 u2^T + (v1 x v2)(u1 x u2)^T over the two dominant singular triplets, which equals the
+// reference's formula for any sign convention of the SVD and for rank-2 H (3-point hypotheses always have sigma3 = 0).
+// Jacobi eigen-decomposition of H^T H in double.
+// =========================================================================================================
+__device__ void sym_eig3(double a[3][3], double v[3][3], double w[3]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    const double dia = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+    if (off <= 1e-300 || off <= 1e-22 * dia) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = a[p][q];
+        if (fabs(apq) <= 1e-300) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        const int r = 3 - p - q;
+        const double app = a[p][p], aqq = a[q][q], arp = a[r][p], arq = a[r][q];
+        a[p][p] = app - tt * apq;
+        a[q][q] = aqq + tt * apq;
+        a[p][q] = a[q][p] = 0.0;
+        a[r][p] = a[p][r] = c * arp - s * arq;
+        a[r][q] = a[q][r] = s * arp + c * arq;
+        for (int i = 0; i < 3; ++i) {
+          const double vip = v[i][p], viq = v[i][q];
+          v[i][p] = c * vip - s * viq;
+          v[i][q] = s * vip + c * viq;
+        }
+      }
+  }
+  w[0] = a[0][0];
+  w[1] = a[1][1];
+  w[2] = a[2][2];
+}
+
+__device__ void rotation_from_H(const double H[9], double R[9]) {
+  double m[3][3], v[3][3], w[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) m[i][j] = H[0 * 3 + i] * H[0 * 3 + j] + H[1 * 3 + i] * H[1 * 3 + j] + H[2 * 3 + i] * H[2 * 3 + j];
+  sym_eig3(m, v, w);
+  int i0 = 0, i1 = 1, i2 = 2;  // sort eigenvalues descending
+  if (w[i0] < w[i1]) { int x = i0; i0 = i1; i1 = x; }
+  if (w[i0] < w[i2]) { int x = i0; i0 = i2; i2 = x; }
+  if (w[i1] < w[i2]) { int x = i1; i1 = i2; i2 = x; }
+  double v1[3] = {v[0][i0], v[1][i0], v[2][i0]};
+  double v2[3] = {v[0][i1], v[1][i1], v[2][i1]};
+  double u1[3], u2[3];
+  for (int i = 0; i < 3; ++i) {
+    u1[i] = H[i * 3 + 0] * v1[0] + H[i * 3 + 1] * v1[1] + H[i * 3 + 2] * v1[2];
+    u2[i] = H[i * 3 + 0] * v2[0] + H[i * 3 + 1] * v2[1] + H[i * 3 + 2] * v2[2];
+  }
+  const double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+  if (!(n1 > 1e-150)) {  // H == 0: no information, identity
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  for (int i = 0; i < 3; ++i) u1[i] /= n1;
+  const double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+  for (int i = 0; i < 3; ++i) u2[i] -= d12 * u1[i];
+  double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  if (!(n2 > 1e-12 * n1)) {  // rank-1 H (degenerate hypothesis): any unit vector orthogonal to u1 (finite, deterministic)
+    const int k = (fabs(u1[0]) <= fabs(u1[1]) && fabs(u1[0]) <= fabs(u1[2])) ? 0 : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0};
+    e[k] = 1.0;
+    const double d = u1[k];
+    for (int i = 0; i < 3; ++i) u2[i] = e[i] - d * u1[i];
+    n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  }
+  for (int i = 0; i < 3; ++i) u2[i] /= n2;
+  const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+  const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = v1[i] * u1[j] + v2[i] * u2[j] + v3[i] * u3[j];
+}
+
+// Coarse hypotheses (model_utils.py:244-257): sample s = 3h+k picks the pair (i1 = idx / N2, i2 = idx % N2);
+// R,t = procrustes(src = p2 triple -> ref = p1 triple), unit weights (thresh 0.5 keeps them), eps 1e-5;
+// dis = mean_k |(p1_k - t) R - p2_k|.
+__global__ __launch_bounds__(256) void coarse_hyp_kernel(const int* __restrict__ idx, const float* __restrict__ pts1,
+                                                         const float* __restrict__ pts2, int N1, int N2, int nh, long total,
+                                                         float* __restrict__ Rs, float* __restrict__ ts, float* __restrict__ dis) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long b = e / nh;
+  const float* P1 = pts1 + b * N1 * 3;
+  const float* P2 = pts2 + b * N2 * 3;
+  double p1[3][3], p2[3][3];
+  for (int k = 0; k < 3; ++k) {
+    const int id = idx[e * 3 + k];
+    const int a = min(id / N2, N1 - 1), c = min(id % N2, N2 - 1);
+    for (int d = 0; d < 3; ++d) {
+      p1[k][d] = (double)P1[a * 3 + d];
+      p2[k][d] = (double)P2[c * 3 + d];
+    }
+  }
+  const double w = (double)(1.0f / (3.0f + 1e-5f));
+  double sc[3], rc[3];
+  for (int d = 0; d < 3; ++d) {
+    sc[d] = (p2[0][d] + p2[1][d] + p2[2][d]) * w;
+    rc[d] = (p1[0][d] + p1[1][d] + p1[2][d]) * w;
+  }
+  double H[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += (p2[k][i] - sc[i]) * (w * (p1[k][j] - rc[j]));
+      H[i * 3 + j] = s;
+    }
+  double R[9], t[3];
+  rotation_from_H(H, R);
+  for (int i = 0; i < 3; ++i) t[i] = rc[i] - (R[i * 3] * sc[0] + R[i * 3 + 1] * sc[1] + R[i * 3 + 2] * sc[2]);
+  double acc = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double r2 = 0.0;
+    for (int j = 0; j < 3; ++j) {
+      const double y = (p1[k][0] - t[0]) * R[0 * 3 + j] + (p1[k][1] - t[1]) * R[1 * 3 + j] + (p1[k][2] - t[2]) * R[2 * 3 + j];
+      const double dd = y - p2[k][j];
+      r2 += dd * dd;
+    }
+    acc += sqrt(r2);
+  }
+  for (int i = 0; i < 9; ++i) Rs[e * 9 + i] = (float)R[i];
+  for (int i = 0; i < 3; ++i) ts[e * 3 + i] = (float)t[i];
+  dis[e] = (float)(acc / 3.0);
+}
+
+extern "C" int sam6d_coarse_hypotheses(const int* idx, const float* pts1, const float* pts2, int B, int N1, int N2, int nh,
+                                       float* Rs, float* ts, float* dis, void* stream) {
+  SAM6D_REQUIRE(idx && pts1 && pts2 && Rs && ts && dis && B >= 0 && N1 > 0 && N2 > 0 && nh >= 0, "coarse_hypotheses: bad arguments");
+  const long total = (long)B * nh;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(coarse_hyp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, pts1,
+                     pts2, N1, N2, nh, total, Rs, ts, dis);
+  SAM6D_LAUNCH_CHECK("coarse_hypotheses");
+}
+
+// k smallest of each row by rank counting: rank_i = #{j : d_j < d_i or (d_j == d_i and j < i)}; sel[rank] = i.
+// Output is sorted ascending (torch.topk(largest=False) order; tie order there is unspecified).
+__global__ __launch_bounds__(256) void select_smallest_kernel(const float* __restrict__ dis, int n, int k, int* __restrict__ sel) {
+  extern __shared__ float sd[];
+  const int b = blockIdx.y;
+  const float* d = dis + (size_t)b * n;
+  for (int i = threadIdx.x; i < n; i += 256) sd[i] = d[i];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = sd[i];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const float o = sd[j];
+    rank += (o < v || (o == v && j < i)) ? 1 : 0;
+  }
+  if (rank < k) sel[(size_t)b * k + rank] = i;
+}
+
+extern "C" int sam6d_select_smallest(const float* dis, int B, int n, int k, int* sel, void* stream) {
+  SAM6D_REQUIRE(dis && sel && B >= 0 && n > 0 && k > 0 && k <= n && n <= 15000 && B <= 65535, "select_smallest: bad arguments (n <= 15000)");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)n * 4, (hipStream_t)stream, dis, n, k, sel);
+  SAM6D_LAUNCH_CHECK("select_smallest");
+}
+
+// Hypothesis scoring (model_utils.py:261-267): score = sum(w1) / (sum_i w1_i * min_m |(p1_i - t) R - model_m| + 1e-8),
+// distances in the pairwise_distance bit recipe, model = model_raw / (radius + 1e-6) (coarse_point_matching.py:60).
+__global__ __launch_bounds__(256) void score_hyp_kernel(const int* __restrict__ sel, const float* __restrict__ Rs,
+                                                        const float* __restrict__ ts, const float* __restrict__ pts1,
+                                                        const float* __restrict__ w1, const float* __restrict__ model,
+                                                        const float* __restrict__ radius, int N1, int P, int nh, int k,
+                                                        float* __restrict__ scores) {
+  extern __shared__ float sm[];  // [P*4]: x,y,z,|m|^2
+  __shared__ float red[2][4];
+  const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
+  const float den = radius[b] + 1e-6f;
+  const float* mb = model + (size_t)b * P * 3;
+  for (int i = t; i < P; i += 256) {
+    const float x = mb[i * 3] / den, y = mb[i * 3 + 1] / den, z = mb[i * 3 + 2] / den;
+    sm[i * 4] = x; sm[i * 4 + 1] = y; sm[i * 4 + 2] = z; sm[i * 4 + 3] = sqnorm3(x, y, z);
+  }
+  const int h = sel[(size_t)b * k + s];
+  const float* R = Rs + ((size_t)b * nh + h) * 9;
+  const float* tt = ts + ((size_t)b * nh + h) * 3;
+  __syncthreads();
+  float sw = 0.f, sdw = 0.f;
+  for (int i = t; i < N1; i += 256) {
+    const float* p = pts1 + ((size_t)b * N1 + i) * 3;
+    const float d0 = p[0] - tt[0], d1 = p[1] - tt[1], d2 = p[2] - tt[2];
+    const float x0 = fmaf(d2, R[6], fmaf(d1, R[3], d0 * R[0]));
+    const float x1 = fmaf(d2, R[7], fmaf(d1, R[4], d0 * R[1]));
+    const float x2 = fmaf(d2, R[8], fmaf(d1, R[5], d0 * R[2]));
+    const float sx = sqnorm3(x0, x1, x2);
+    float mn = INFINITY;
+    for (int m = 0; m < P; ++m) {
+      const float4 q = *reinterpret_cast<const float4*>(&sm[m * 4]);
+      mn = fminf(mn, pdist3(x0, x1, x2, sx, q.x, q.y, q.z, q.w));
+    }
+    const float wv = w1[(size_t)b * N1 + i];
+    sw += wv;
+    sdw += sqrtf(mn) * wv;
+  }
+  sw = wave_sum(sw);
+  sdw = wave_sum(sdw);
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = sw;
+    red[1][t >> 6] = sdw;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float c = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    scores[(size_t)b * k + s] = a / (c + 1e-8f);
+  }
+}
+
+// argmax over the k scored hypotheses (first maximum, model_utils.py:268) -> R (B,3,3), t (B,3)
+__global__ __launch_bounds__(64) void pick_best_kernel(const float* __restrict__ scores, const int* __restrict__ sel,
+                                                       const float* __restrict__ Rs, const float* __restrict__ ts, int nh, int k,
+                                                       float* __restrict__ R, float* __restrict__ t, int* __restrict__ best_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < k; i += 64) {
+    const float v = scores[(size_t)b * k + i];
+    if (v > best) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (bi == 0x7fffffff) bi = 0;
+  const int h = sel[(size_t)b * k + bi];
+  if (lane < 9) R[b * 9 + lane] = Rs[((size_t)b * nh + h) * 9 + lane];
+  if (lane < 3) t[b * 3 + lane] = ts[((size_t)b * nh + h) * 3 + lane];
+  if (lane == 0 && best_out) best_out[b] = h;
+}
+
+extern "C" int sam6d_score_select_hypotheses(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,
+                                             const float* model, const float* radius, int B, int N1, int P, int nh, int k,
+                                             float* scores, float* R, float* t, int* best, void* stream) {
+  SAM6D_REQUIRE(sel && Rs && ts && pts1 && w1 && model && radius && scores && R && t, "score_select_hypotheses: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N1 > 0 && P > 0 && P <= 8192 && k > 0 && B <= 65535, "score_select_hypotheses: bad sizes (P <= 8192)");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(score_hyp_kernel, dim3(k, B), dim3(256), (size_t)P * 16, s, sel, Rs, ts, pts1, w1, model, radius, N1, P, nh, k,
+                     scores);
+  hipLaunchKernelGGL(pick_best_kernel, dim3(B), dim3(64), 0, s, scores, sel, Rs, ts, nh, k, R, t, best);
+  SAM6D_LAUNCH_CHECK("score_select_hypotheses");
+}
+
+// =========================================================================================================
+// Fine pose (model_utils.py:308-341)
+// =========================================================================================================
+// per row r >= 1:  A[r,c] = S[r,c] * [l1>0] * [l2>0]  (c >= 1);  weight = sum_c A;  pred = sum_c (A / (weight + 1e-6)) p2[c-1]
+__global__ __launch_bounds__(256) void fine_assign_kernel(const float* __restrict__ att, int R, int C, long rows,
+                                                          const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                          const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                          const int* __restrict__ label1, const int* __restrict__ label2,
+                                                          const float* __restrict__ pts2, float* __restrict__ pred,
+                                                          float* __restrict__ weight) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*(R-1)
+  if (w >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long b = w / (R - 1);
+  const int r = (int)(w % (R - 1)) + 1;
+  const float* a = att + ((size_t)b * R + r) * C;
+  const float rm = rmax[b * R + r], rs = rsum[b * R + r];
+  const float* cm = cmax + b * C;
+  const float* cs = csum + b * C;
+  const int* l2 = label2 + b * (C - 1);
+  const float* p2 = pts2 + b * (C - 1) * 3;
+  const float f1 = label1[w] > 0 ? 1.f : 0.f;
+  float sa = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int c = 1 + lane; c < C; c += 64) {
+    float v = sa_value(a[c], rm, rs, cm[c], cs[c]);
+    v = (v * f1) * (l2[c - 1] > 0 ? 1.f : 0.f);
+    sa += v;
+    sx = fmaf(v, p2[(c - 1) * 3], sx);
+    sy = fmaf(v, p2[(c - 1) * 3 + 1], sy);
+    sz = fmaf(v, p2[(c - 1) * 3 + 2], sz);
+  }
+  sa = wave_sum(sa); sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  if (lane == 0) {
+    const float den = sa + 1e-6f;
+    weight[w] = sa;
+    pred[w * 3] = sx / den;
+    pred[w * 3 + 1] = sy / den;
+    pred[w * 3 + 2] = sz / den;
+  }
+}
+
+extern "C" int sam6d_fine_assign(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
+                                 const float* csum, const int* label1, const int* label2, const float* pts2, float* pred,
+                                 float* weight, void* stream) {
+  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && pts2 && pred && weight, "fine_assign: null pointer");
+  const long rows = (long)B * (R - 1);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(fine_assign_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, R, C, rows, rmax,
+                     rsum, cmax, csum, label1, label2, pts2, pred, weight);
+  SAM6D_LAUNCH_CHECK("fine_assign");
+}
+
+// N-point weighted Procrustes, one workgroup per batch element (model_utils.py:343-436):
+// w <- where(w < thresh, 0, w);  w <- w / (sum w + eps);  centroids;  H = sum (src - sc)^T (w (ref - rc));  R, t.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                         const float* __restrict__ wts, int N, float thresh, float eps,
+                                                         float* __restrict__ Rout, float* __restrict__ tout) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* S = src + (size_t)b * N * 3;
+  const float* Q = ref + (size_t)b * N * 3;
+  const float* W = wts ? wts + (size_t)b * N : nullptr;
+  double sw = 0.0;
+  for (int i = t; i < N; i += 256) {
+    float w = W ? W[i] : 1.0f;
+    if (w < thresh) w = 0.f;
+    sw += (double)w;
+  }
+  sw = block_sum_d(sw, red);
+  const float den = (float)sw + eps;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = t; i < N; i += 256) {
+    float w = W ? W[i] : 1.0f;
+    if (w < thresh) w = 0.f;
+    const double wn = (double)(w / den);
+    for (int d = 0; d < 3; ++d) {
+      c[d] += (double)S[i * 3 + d] * wn;
+      c[3 + d] += (double)Q[i * 3 + d] * wn;
+    }
+  }
+  for (int d = 0; d < 6; ++d) c[d] = block_sum_d(c[d], red);
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = t; i < N; i += 256) {
+    float w = W ? W[i] : 1.0f;
+    if (w < thresh) w = 0.f;
+    const double wn = (double)(w / den);
+    double s[3], q[3];
+    for (int d = 0; d < 3; ++d) {
+      s[d] = (double)S[i * 3 + d] - c[d];
+      q[d] = wn * ((double)Q[i * 3 + d] - c[3 + d]);
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int d = 0; d < 3; ++d) H[a * 3 + d] += s[a] * q[d];
+  }
+  for (int d = 0; d < 9; ++d) H[d] = block_sum_d(H[d], red);
+  if (t == 0) {
+    double R[9];
+    rotation_from_H(H, R);
+    for (int i = 0; i < 9; ++i) Rout[b * 9 + i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) tout[b * 3 + i] = (float)(c[3 + i] - (R[i * 3] * c[0] + R[i * 3 + 1] * c[1] + R[i * 3 + 2] * c[2]));
+  }
+}
+
+extern "C" int sam6d_weighted_procrustes(const float* src, const float* ref, const float* weights, int B, int N, float weight_thresh,
+                                         float eps, float* R, float* t, void* stream) {
+  SAM6D_REQUIRE(src && ref && R && t && B >= 0 && N > 0, "weighted_procrustes: bad arguments");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(procrustes_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, src, ref, weights, N, weight_thresh, eps, R, t);
+  SAM6D_LAUNCH_CHECK("weighted_procrustes");
+}
+
+// Fine pose score (model_utils.py:331-339):  dis_i = min_m |(p1_i - t) R - model_m|;  mask = [label1 > 0];
+// score = sum([dis < thr] * mask) / (sum(mask) + 1e-8) * mean(mask);  t_out = t * (radius + 1e-6) (fine_point_matching.py:78)
+__global__ __launch_bounds__(256) void fine_near_kernel(const float* __restrict__ pts1, const float* __restrict__ R,
+                                                        const float* __restrict__ t, const float* __restrict__ model,
+                                                        const float* __restrict__ radius, const int* __restrict__ label1, int N,
+                                                        int P, float thr, float* __restrict__ cnt) {
+  extern __shared__ float sm[];
+  __shared__ float red[2][4];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float den = radius[b] + 1e-6f;
+  const float* mb = model + (size_t)b * P * 3;
+  for (int i = tid; i < P; i += 256) {
+    const float x = mb[i * 3] / den, y = mb[i * 3 + 1] / den, z = mb[i * 3 + 2] / den;
+    sm[i * 4] = x; sm[i * 4 + 1] = y; sm[i * 4 + 2] = z; sm[i * 4 + 3] = sqnorm3(x, y, z);
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + tid;
+  float near = 0.f, mk = 0.f;
+  if (i < N) {
+    const float* Rb = R + b * 9;
+    const float* p = pts1 + ((size_t)b * N + i) * 3;
+    const float d0 = p[0] - t[b * 3], d1 = p[1] - t[b * 3 + 1], d2 = p[2] - t[b * 3 + 2];
+    const float x0 = fmaf(d2, Rb[6], fmaf(d1, Rb[3], d0 * Rb[0]));
+    const float x1 = fmaf(d2, Rb[7], fmaf(d1, Rb[4], d0 * Rb[1]));
+    const float x2 = fmaf(d2, Rb[8], fmaf(d1, Rb[5], d0 * Rb[2]));
+    const float sx = sqnorm3(x0, x1, x2);
+    float mn = INFINITY;
+    for (int m = 0; m < P; ++m) {
+      const float4 q = *reinterpret_cast<const float4*>(&sm[m * 4]);
+      mn = fminf(mn, pdist3(x0, x1, x2, sx, q.x, q.y, q.z, q.w));
+    }
+    mk = label1[(size_t)b * N + i] > 0 ? 1.f : 0.f;
+    near = (sqrtf(mn) < thr) ? mk : 0.f;
+  }
+  near = wave_sum(near);
+  mk = wave_sum(mk);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = near; red[1][tid >> 6] = mk; }
+  __syncthreads();
+  if (tid == 0) {  // integer-valued partial sums: exact in fp32 whatever the arrival order
+    atomicAdd(&cnt[b * 2], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(&cnt[b * 2 + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+__global__ void zero_kernel(float* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+__global__ void fine_finish_kernel(const float* __restrict__ cnt, const float* __restrict__ radius, int B, int N,
+                                   float* __restrict__ t, float* __restrict__ score) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float near = cnt[b * 2], mk = cnt[b * 2 + 1];
+  score[b] = (near / (mk + 1e-8f)) * (mk / (float)N);
+  const float s = radius[b] + 1e-6f;
+  t[b * 3] *= s; t[b * 3 + 1] *= s; t[b * 3 + 2] *= s;
+}
+
+extern "C" int sam6d_fine_score(const float* pts1, const float* R, float* t, const float* model, const float* radius,
+                                const int* label1, int B, int N, int P, float dis_thres, float* cnt_ws, float* score, void* stream) {
+  SAM6D_REQUIRE(pts1 && R && t && model && radius && label1 && cnt_ws && score, "fine_score: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && P > 0 && P <= 8192 && B <= 65535, "fine_score: bad sizes (P <= 8192)");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(zero_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, cnt_ws, 2 * B);
+  hipLaunchKernelGGL(fine_near_kernel, dim3(cdiv(N, 256), B), dim3(256), (size_t)P * 16, s, pts1, R, t, model, radius, label1, N, P,
+                     dis_thres, cnt_ws);
+  hipLaunchKernelGGL(fine_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, cnt_ws, radius, B, N, t, score);
+  SAM6D_LAUNCH_CHECK("fine_score");
+}

@@ -22,6 +22,30 @@ SIGNATURES = {
     "sam6d_ball_query": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
+    "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
+    "sam6d_layernorm256": [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_f, c_p],
+    "sam6d_geo_embedding": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p],
+    "sam6d_attention": [c_p] * 6 + [c_i] * 3 + [c_l] * 8 + [c_p],
+    "sam6d_linattn_focus_k": [c_p, c_p, c_l, c_l, c_p],
+    "sam6d_linattn_kv": [c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p, c_p, c_p],
+    "sam6d_linattn_focus_q": [c_p, c_p, c_p, c_i, c_l, c_l, c_p],
+    "sam6d_pe_group_rows": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_group_max": [c_p, c_l, c_i, c_i, c_l, c_i, c_p, c_p],
+    "sam6d_rigid_inverse": [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
+    "sam6d_put_rows": [c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p],
+    "sam6d_prepend_bg_point": [c_p, c_i, c_i, c_p, c_p],
+    "sam6d_add_scalar": [c_p, c_f, c_l, c_p, c_p],
+    "sam6d_copy_f32": [c_p, c_p, c_l, c_p],
+    "sam6d_l2norm256": [c_p, c_p, c_l, c_l, c_l, c_p],
+    "sam6d_soft_assign": [c_p, c_i, c_i, c_i] + [c_p] * 7,
+    "sam6d_coarse_weights": [c_p, c_i, c_i, c_i] + [c_p] * 9,
+    "sam6d_weighted_sample": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_coarse_hypotheses": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "sam6d_select_smallest": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_score_select_hypotheses": [c_p] * 7 + [c_i] * 5 + [c_p] * 5,
+    "sam6d_fine_assign": [c_p, c_i, c_i, c_i] + [c_p] * 10,
+    "sam6d_weighted_procrustes": [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
+    "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
 }
 
 _lib = None

@@ -1,0 +1,438 @@
+"""Host orchestration of the PEM geometric-matching path on one MI355X.
+
+The reference's Python modules call torch ops; this module issues the equivalent sequence of libsam6d_hip.so launches
+on torch's current HIP stream.  torch is used for device buffers only (torch.empty) -- no torch arithmetic on the
+path.  Everything that shares weights between the scene cloud and the template cloud (geo embedding, in_proj, PE, the
+RPE self layers, the dense linear-attention layers, out_proj) runs ONCE on a stacked (2B, ...) batch; only the
+sequential cross-attention halves (PEM/model/transformer.py:520-521) are issued per cloud.
+
+Citations: PEM = SAM-6D/Pose_Estimation_Model in the reference.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+C = 256
+H = 4
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, off=0):
+    return t.data_ptr() + 4 * off if t is not None else None
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------- weight packing
+class Linear:
+    __slots__ = ("w", "b")
+
+    def __init__(self, w, b):
+        self.w, self.b = w.contiguous(), (b.contiguous() if b is not None else None)
+
+
+class PemWeights:
+    """Device-resident weights in the layouts the kernels want, built from a reference-keyed state_dict
+    (SURVEY 8b B2).  Packing is pure data movement: concatenating q/k/v projection weights, transposing proj_p, folding
+    eval-mode BatchNorm into a per-channel scale/shift."""
+
+    def __init__(self, sd, device, nblock=3):
+        g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        self.dev = device
+        self.nblock = nblock
+        self.div_term = g("geo_embedding.embedding.div_term")
+        self.geo_d = Linear(g("geo_embedding.proj_d.weight"), g("geo_embedding.proj_d.bias"))
+        self.geo_a = Linear(g("geo_embedding.proj_a.weight"), g("geo_embedding.proj_a.bias"))
+        self.coarse = self._matching(g, "coarse_point_matching")
+        self.fine = self._matching(g, "fine_point_matching")
+        self.coarse["blocks"] = [self._geo_transformer(g, "coarse_point_matching.transformers.%d" % i) for i in range(nblock)]
+        self.fine["blocks"] = []
+        for i in range(nblock):
+            t = "fine_point_matching.transformers.%d" % i
+            blk = self._geo_transformer(g, t + ".sparse_layer")
+            d = t + ".dense_layer"
+            a = d + ".attention.attention"
+            blk["dense"] = dict(
+                scale=g(a + ".scale").reshape(-1),
+                q=Linear(g(a + ".proj_q.weight"), g(a + ".proj_q.bias")),
+                kv=Linear(torch.cat([g(a + ".proj_k.weight"), g(a + ".proj_v.weight")], 0),
+                          torch.cat([g(a + ".proj_k.bias"), g(a + ".proj_v.bias")], 0)),
+                **self._post(g, d))
+            self.fine["blocks"].append(blk)
+        pe = "fine_point_matching.PE"
+        self.pe = dict(mlp=[], mlp3=Linear(g(pe + ".mlp3.conv.weight").reshape(C, C), g(pe + ".mlp3.conv.bias")))
+        for k in (1, 2):
+            layers = []
+            for l in range(3):
+                q = "%s.mlp%d.layer%d" % (pe, k, l)
+                w = g(q + ".conv.weight")
+                w = w.reshape(w.shape[0], w.shape[1]).contiguous()
+                bn = q + ".normlayer.bn"
+                scale = g(bn + ".weight") / torch.sqrt(g(bn + ".running_var") + 1e-5)
+                shift = g(bn + ".bias") - g(bn + ".running_mean") * scale
+                layers.append(dict(w=w, scale=scale.contiguous(), shift=shift.contiguous()))
+            self.pe["mlp"].append(layers)
+
+    @staticmethod
+    def _matching(g, p):
+        return dict(bg=g(p + ".bg_token").reshape(1, C), in_proj=Linear(g(p + ".in_proj.weight"), g(p + ".in_proj.bias")),
+                    out_proj=Linear(g(p + ".out_proj.weight"), g(p + ".out_proj.bias")))
+
+    @staticmethod
+    def _post(g, p):
+        return dict(lin=Linear(g(p + ".attention.linear.weight"), g(p + ".attention.linear.bias")),
+                    n1=(g(p + ".attention.norm.weight"), g(p + ".attention.norm.bias")),
+                    exp=Linear(g(p + ".output.expand.weight"), g(p + ".output.expand.bias")),
+                    sq=Linear(g(p + ".output.squeeze.weight"), g(p + ".output.squeeze.bias")),
+                    n2=(g(p + ".output.norm.weight"), g(p + ".output.norm.bias")))
+
+    def _geo_transformer(self, g, p):
+        s, c = p + ".layers.0", p + ".layers.1"
+        sa, ca = s + ".attention.attention", c + ".attention.attention"
+        self_l = dict(
+            qkv=Linear(torch.cat([g(sa + ".proj_q.weight"), g(sa + ".proj_k.weight"), g(sa + ".proj_v.weight")], 0),
+                       torch.cat([g(sa + ".proj_q.bias"), g(sa + ".proj_k.bias"), g(sa + ".proj_v.bias")], 0)),
+            # proj_p folded into the query (attention.hip header): WpT[j, k] = Wp[k, j]; its bias cancels in softmax
+            wpT=g(sa + ".proj_p.weight").t().contiguous(),
+            **self._post(g, s))
+        cross_l = dict(
+            q=Linear(g(ca + ".proj_q.weight"), g(ca + ".proj_q.bias")),
+            kv=Linear(torch.cat([g(ca + ".proj_k.weight"), g(ca + ".proj_v.weight")], 0),
+                      torch.cat([g(ca + ".proj_k.bias"), g(ca + ".proj_v.bias")], 0)),
+            **self._post(g, c))
+        return dict(self=self_l, cross=cross_l)
+
+
+# ------------------------------------------------------------------------------------------------- primitives
+def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, residual=None, r_off=0, ldr=0,
+         colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0):
+    _lib.call("sam6d_gemm_nt", _p(A, a_off), _p(W, w_off), _p(bias), _p(colscale), _p(residual, r_off), _p(out, c_off),
+              M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR, float(divisor), act, _s())
+
+
+def linear(x2d, lin, *, act=0, residual=None, out=None):
+    """x2d (M,K) contiguous -> (M,N) = act(x W^T + b) (+ residual)."""
+    M, K = x2d.shape
+    N = lin.w.shape[0]
+    if out is None:
+        out = _empty((M, N), x2d)
+    gemm(x2d, lin.w, lin.b, out, M, N, K, K, K, N, residual=residual, ldr=N, act=act)
+    return out
+
+
+def layernorm(x2d, gb, out=None):
+    rows = x2d.shape[0]
+    if out is None:
+        out = torch.empty_like(x2d)
+    _lib.call("sam6d_layernorm256", _p(x2d), _p(gb[0]), _p(gb[1]), _p(out), rows, C, C, 1e-5, _s())
+    return out
+
+
+def _post_attention(hidden, x2d, L):
+    """linear -> +residual -> LayerNorm -> AttentionOutput (expand, ReLU, squeeze, +residual, LayerNorm)
+    (PEM/model/transformer.py:152-199)."""
+    y = layernorm(linear(hidden, L["lin"], residual=x2d), L["n1"])
+    h = linear(y, L["exp"], act=1)
+    return layernorm(linear(h, L["sq"], residual=y), L["n2"])
+
+
+def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
+    """points_bg (B,n,3) with the bg point prepended -> (B,n,n,256)   (PEM/model/transformer.py:343-363)."""
+    B, n, _ = points_bg.shape
+    out = _empty((B, n, n, C), points_bg)
+    knn = _empty((B, n, angle_k), points_bg, torch.int32)
+    idx = _empty((B, n, n, 4), points_bg)
+    factor_a = 180.0 / (sigma_a * math.pi)
+    _lib.call("sam6d_geo_embedding", _p(points_bg), B, n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
+              _p(W.geo_a.b), float(sigma_d), float(factor_a), angle_k, C, _p(knn), _p(idx), _p(out), _s())
+    return out
+
+
+def rpe_self_layer(x, E, L):
+    """x (B',n,256), E (B',n,n,256) -> (B',n,256)   RPETransformerLayer (PEM/model/transformer.py:366-479)."""
+    Bp, n, _ = x.shape
+    M = Bp * n
+    x2 = x.reshape(M, C)
+    qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
+    qp = _empty((M, H * C), x)
+    # qp[:, h, :] = q_h @ Wp[h*64:(h+1)*64, :]  -- 4 head problems as one batched launch
+    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C)
+    hid = _empty((M, C), x)
+    _lib.call("sam6d_attention", _p(qkv), _p(qkv, C), _p(qkv, 2 * C), _p(qp), _p(E), _p(hid), Bp, n, n, 3 * C, 3 * C, 3 * C,
+              C, n * 3 * C, n * 3 * C, n * 3 * C, n * C, _s())
+    return _post_attention(hid, x2, L).reshape(Bp, n, C)
+
+
+def cross_layer(x, mem, L):
+    """x (B,n,256) attends to mem (B,m,256)   TransformerLayer (PEM/model/transformer.py:95-226)."""
+    B, n, _ = x.shape
+    m = mem.shape[1]
+    x2 = x.reshape(B * n, C)
+    q = linear(x2, L["q"])
+    kv = linear(mem.reshape(B * m, C), L["kv"])  # (B*m, 512): k | v
+    hid = _empty((B * n, C), x)
+    _lib.call("sam6d_attention", _p(q), _p(kv), _p(kv, C), None, None, _p(hid), B, n, m, C, 2 * C, 2 * C, C, n * C, m * 2 * C,
+              m * 2 * C, n * C, _s())
+    return _post_attention(hid, x2, L).reshape(B, n, C)
+
+
+def geometric_transformer(S, E, T):
+    """S (2B,n,256) stacked [scene; template], E (2B,n,n,256) -> same shape
+    (GeometricTransformer blocks ['self','cross'], sequential cross: PEM/model/transformer.py:483-527)."""
+    B = S.shape[0] // 2
+    S = rpe_self_layer(S, E, T["self"])
+    f0 = cross_layer(S[:B], S[B:], T["cross"])
+    f1 = cross_layer(S[B:], f0, T["cross"])
+    return _stack(f0, f1)
+
+
+def _stack(a, b):
+    out = _empty((a.shape[0] * 2,) + tuple(a.shape[1:]), a)
+    rows = a.shape[1]
+    _lib.call("sam6d_put_rows", _p(a), rows * C, C, _p(out), rows * C, C, a.shape[0], rows, C, _s())
+    _lib.call("sam6d_put_rows", _p(b), rows * C, C, _p(out, a.shape[0] * rows * C), rows * C, C, b.shape[0], rows, C, _s())
+    return out
+
+
+def linear_transformer_layer(D, S, L):
+    """D (B',I,256) dense tokens (row 0 = bg slot, recomputed by the caller), S (B',J+1,256) sparse tokens (row 0 = bg).
+    LinearTransformerLayer on D[:,1:] with memory S[:,1:] (PEM/model/transformer.py:581-622, 707-719); the bg rows of
+    D ride along through the row kernels and are overwritten afterwards."""
+    Bp, I, _ = D.shape
+    J = S.shape[1] - 1
+    rows = Bp * I
+    D2 = D.reshape(rows, C)
+    q = linear(D2, L["q"])
+    kv = _empty((Bp, J, 2 * C), D)
+    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C)
+    if not (I * J * 128 > 64 * 64 * (I + J)):
+        raise RuntimeError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
+    _lib.call("sam6d_linattn_focus_k", _p(kv), _p(L["scale"]), Bp * J, 2 * C, _s())
+    kvT = _empty((Bp, H, 64, 64), D)
+    ksum = _empty((Bp, H, 64), D)
+    _lib.call("sam6d_linattn_kv", _p(kv), _p(kv, C), Bp, J, 2 * C, 2 * C, J * 2 * C, J * 2 * C, _p(kvT), _p(ksum), _s())
+    _lib.call("sam6d_linattn_focus_q", _p(q), _p(L["scale"]), _p(ksum), Bp, I, C, _s())
+    hid = _empty((rows, C), D)
+    for h in range(H):  # x_h = (phi(q)_h z) @ kv_h : batched over B'
+        gemm(q, kvT, None, hid, I, 64, 64, C, 64, C, a_off=h * 64, w_off=h * 4096, c_off=h * 64, batch=Bp, sA=I * C,
+             sW=H * 4096, sC=I * C)
+    return _post_attention(hid, D2, L).reshape(Bp, I, C)
+
+
+def sparse_to_dense_transformer(D, E, fps_idx, T):
+    """D (2B,N+1,256) dense tokens incl. bg row, E (2B,n,n,256), fps_idx (2B,n-1) i32 -> new D
+    (SparseToDenseTransformer, PEM/model/transformer.py:627-720, incl. the index-into-the-cat quirk :667-705)."""
+    Bp, I, _ = D.shape
+    n1 = fps_idx.shape[1]
+    S = _empty((Bp, n1 + 1, C), D)
+    _lib.call("sam6d_gather_rows", _p(D), _p(fps_idx), Bp, I, n1, C, I * C, (n1 + 1) * C, 0, _p(S, C), _s())
+    _lib.call("sam6d_put_rows", _p(D), I * C, C, _p(S), (n1 + 1) * C, C, Bp, 1, C, _s())
+    S = geometric_transformer(S, E, T)
+    Dn = linear_transformer_layer(D, S, T["dense"])
+    _lib.call("sam6d_put_rows", _p(S), (n1 + 1) * C, C, _p(Dn), I * C, C, Bp, 1, C, _s())
+    return Dn
+
+
+def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32, ns2=64):
+    """dst[b, 1 + i, :] += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2)))   (PositionalEncoding,
+    PEM/model/fine_point_matching.py:102-144).  pts (B',N,3); dst rows addressed by (dst_off, batch stride dst_sb)."""
+    Bp, N, _ = pts.shape
+    feat = _empty((Bp * N, 2 * 128), pts)
+    q = _empty((Bp, N, 3), pts)  # new_xyz = pts + 1e-8 (fine_point_matching.py:117)
+    _lib.call("sam6d_add_scalar", _p(pts), 0.00000001, Bp * N * 3, _p(q), _s())
+    for k, (r, ns) in enumerate(((r1, ns1), (r2, ns2))):
+        idx = _empty((Bp, N, ns), pts, torch.int32)
+        _lib.call("sam6d_ball_query", _p(q), _p(pts), Bp, N, N, float(r), ns, _p(idx), _s())
+        rows = Bp * N * ns
+        x = _empty((rows, 6), pts)
+        _lib.call("sam6d_pe_group_rows", _p(pts), _p(idx), Bp, N, ns, _p(x), _s())
+        kin = 6
+        for l, lay in enumerate(W.pe["mlp"][k]):
+            nout = lay["w"].shape[0]
+            y = _empty((rows, nout), pts)
+            gemm(x, lay["w"], lay["shift"], y, rows, nout, kin, kin, kin, nout, colscale=lay["scale"], act=1)
+            x, kin = y, nout
+        _lib.call("sam6d_group_max", _p(x), Bp * N, ns, 128, 2 * 128, k * 128, _p(feat), _s())
+    m3 = W.pe["mlp3"]
+    gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
+         sC=dst_sb, sR=dst_sb)
+
+
+def feature_similarity(F, B, n, out_proj, temp):
+    """F (2B,n,256) -> atten (B,n,n) = normalize(out_proj(F0)) @ normalize(out_proj(F1))^T / temp
+    (PEM/utils/model_utils.py:131-153)."""
+    f = linear(F.reshape(2 * B * n, C), out_proj)
+    _lib.call("sam6d_l2norm256", _p(f), _p(f), 2 * B * n, C, C, _s())
+    att = _empty((B, n, n), F)
+    gemm(f, f, None, att, n, n, C, C, C, n, w_off=B * n * C, batch=B, sA=n * C, sW=n * C, sC=n * n, divisor=temp)
+    return att
+
+
+def soft_assign(att):
+    B, R, Cn = att.shape
+    st = dict(rmax=_empty((B, R), att), rsum=_empty((B, R), att), cmax=_empty((B, Cn), att), csum=_empty((B, Cn), att),
+              l1=_empty((B, R - 1), att, torch.int32), l2=_empty((B, Cn - 1), att, torch.int32))
+    _lib.call("sam6d_soft_assign", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
+              _p(st["l1"]), _p(st["l2"]), _s())
+    return st
+
+
+def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_proposal2=300, return_aux=False):
+    """PEM/utils/model_utils.py:204-275.  model (B,P,3) RAW CAD points and radius (B,): the division
+    model / (radius + 1e-6) of coarse_point_matching.py:60 happens inside the scoring kernel.
+    rand (B, 3*n_proposal1): the uniforms the reference draws with torch.rand (model_utils.py:292)."""
+    B, R, Cn = att.shape
+    N1, N2 = R - 1, Cn - 1
+    st = soft_assign(att)
+    L = N1 * N2
+    w = _empty((B, L), att)
+    w1 = _empty((B, N1), att)
+    _lib.call("sam6d_coarse_weights", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
+              _p(st["l1"]), _p(st["l2"]), _p(w), _p(w1), _s())
+    ns = 3 * n_proposal1
+    cum = _empty((B, L), att)
+    idx = _empty((B, ns), att, torch.int32)
+    _lib.call("sam6d_weighted_sample", _p(w), _p(rand), B, L, ns, _p(cum), _p(idx), _s())
+    Rs = _empty((B, n_proposal1, 9), att)
+    ts = _empty((B, n_proposal1, 3), att)
+    dis = _empty((B, n_proposal1), att)
+    _lib.call("sam6d_coarse_hypotheses", _p(idx), _p(pts1), _p(pts2), B, N1, N2, n_proposal1, _p(Rs), _p(ts), _p(dis), _s())
+    sel = _empty((B, n_proposal2), att, torch.int32)
+    _lib.call("sam6d_select_smallest", _p(dis), B, n_proposal1, n_proposal2, _p(sel), _s())
+    scores = _empty((B, n_proposal2), att)
+    Rb = _empty((B, 3, 3), att)
+    tb = _empty((B, 3), att)
+    best = _empty((B,), att, torch.int32)
+    _lib.call("sam6d_score_select_hypotheses", _p(sel), _p(Rs), _p(ts), _p(pts1), _p(w1), _p(model), _p(radius), B, N1,
+              model.shape[1], n_proposal1, n_proposal2, _p(scores), _p(Rb), _p(tb), _p(best), _s())
+    if return_aux:
+        return Rb, tb, dict(weights=w, w1=w1, idx=idx, dis=dis, top=sel, scores=scores, best=best, Rs=Rs, ts=ts, cum=cum)
+    return Rb, tb
+
+
+def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
+    """PEM/utils/model_utils.py:343-436: (B,N,3) x2 [+ (B,N)] -> R (B,3,3), t (B,3)."""
+    B, N, _ = src.shape
+    R = _empty((B, 3, 3), src)
+    t = _empty((B, 3), src)
+    _lib.call("sam6d_weighted_procrustes", _p(src), _p(ref), _p(weights), B, N, float(weight_thresh), float(eps), _p(R),
+              _p(t), _s())
+    return R, t
+
+
+def compute_fine_Rt(att, pts1, pts2, model, radius, dis_thres=0.15):
+    """PEM/utils/model_utils.py:308-341 + the translation rescale of fine_point_matching.py:78.
+    Returns R (B,3,3), t (B,3) already multiplied by (radius + 1e-6), score (B,)."""
+    B, R_, Cn = att.shape
+    st = soft_assign(att)
+    pred = _empty((B, R_ - 1, 3), att)
+    wgt = _empty((B, R_ - 1), att)
+    _lib.call("sam6d_fine_assign", _p(att), B, R_, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
+              _p(st["l1"]), _p(st["l2"]), _p(pts2), _p(pred), _p(wgt), _s())
+    R, t = weighted_procrustes(pred, pts1, wgt, 0.0)
+    cnt = _empty((B, 2), att)
+    score = _empty((B,), att)
+    _lib.call("sam6d_fine_score", _p(pts1), _p(R), _p(t), _p(model), _p(radius), _p(st["l1"]), B, R_ - 1, model.shape[1],
+              float(dis_thres), _p(cnt), _p(score), _s())
+    return R, t, score
+
+
+# --------------------------------------------------------------------------------------------------- modules
+def sample_pts_feats(pts, feats, npoint):
+    """PEM/utils/model_utils.py:70-84 on (B',N,3) / (B',N,C): FPS + two row gathers."""
+    Bp, N, _ = pts.shape
+    idx = _empty((Bp, npoint), pts, torch.int32)
+    temp = _empty((Bp, N), pts) if N > 4096 else None
+    _lib.call("sam6d_furthest_point_sampling", _p(pts), Bp, N, npoint, _p(temp), _p(idx), _s())
+    sp = _empty((Bp, npoint, 3), pts)
+    _lib.call("sam6d_gather_rows", _p(pts), _p(idx), Bp, N, npoint, 3, N * 3, npoint * 3, 0, _p(sp), _s())
+    Cf = feats.shape[2]
+    sf = _empty((Bp, npoint, Cf), pts)
+    _lib.call("sam6d_gather_rows", _p(feats), _p(idx), Bp, N, npoint, Cf, N * Cf, npoint * Cf, 0, _p(sf), _s())
+    return sp, sf, idx
+
+
+def _tokens_with_bg(x, lin, bg, extra=None):
+    """cat([bg_token, in_proj(x)], dim=1) for stacked x (B',N,256) -> (B',N+1,256)
+    (PEM/model/coarse_point_matching.py:35-38, fine_point_matching.py:47-51)."""
+    Bp, N, K = x.shape
+    T = _empty((Bp, N + 1, C), x)
+    gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C)
+    _lib.call("sam6d_put_rows", _p(bg), 0, C, _p(T), (N + 1) * C, C, Bp, 1, C, _s())
+    return T
+
+
+def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=False):
+    """sp (2B,n,3), sf (2B,n,256) stacked [scene; template]  (PEM/model/coarse_point_matching.py:32-63, eval)."""
+    B = sp.shape[0] // 2
+    n = sp.shape[1]
+    S = _tokens_with_bg(sf, W.coarse["in_proj"], W.coarse["bg"])
+    for blk in W.coarse["blocks"]:
+        S = geometric_transformer(S, E, blk)
+    att = feature_similarity(S, B, n + 1, W.coarse["out_proj"], cfg["temp"])
+    out = compute_coarse_Rt(att, sp[:B], sp[B:], model, radius, rand, cfg["nproposal1"], cfg["nproposal2"], return_aux)
+    if return_aux:
+        out[2]["atten"] = att
+    return out
+
+
+def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False):
+    """dp (2B,N,3), df (2B,N,256) stacked [scene; template]  (PEM/model/fine_point_matching.py:42-79, eval)."""
+    Bp, N, _ = dp.shape
+    B = Bp // 2
+    pe_pts = _empty((Bp, N, 3), dp)
+    _lib.call("sam6d_rigid_inverse", _p(dp), _p(init_R), _p(init_t), B, N, _p(pe_pts), _s())  # p1_ = (p1 - t) @ R
+    _lib.call("sam6d_copy_f32", _p(dp, B * N * 3), _p(pe_pts, B * N * 3), B * N * 3, _s())   # p2 unchanged
+    D = _tokens_with_bg(df, W.fine["in_proj"], W.fine["bg"])
+    positional_encoding_add(pe_pts, W, D, C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"],
+                            cfg["pe_nsample2"])
+    for blk in W.fine["blocks"]:
+        D = sparse_to_dense_transformer(D, E, fps_idx, blk)
+    att = feature_similarity(D, B, N + 1, W.fine["out_proj"], cfg["temp"])
+    R, t, score = compute_fine_Rt(att, dp[:B], dp[B:], model, radius, cfg["dis_thres"])
+    if return_aux:
+        return R, t, score, dict(atten=att)
+    return R, t, score
+
+
+DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0.1, nproposal1=6000, nproposal2=300,
+                   pe_radius1=0.1, pe_radius2=0.2, pe_nsample1=32, pe_nsample2=64, dis_thres=0.15)
+
+
+def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False):
+    """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
+    FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
+    rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292)."""
+    B = dense_pm.shape[0]
+    dp = _cat0(dense_pm, dense_po)
+    df = _cat0(dense_fm, dense_fo)
+    n = cfg["coarse_npoint"]
+    sp, sf, idx = sample_pts_feats(dp, df, n)
+    pb = _empty((2 * B, n + 1, 3), dp)
+    _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * B, n, _p(pb), _s())
+    E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    c = coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux)
+    R0, t0 = c[0], c[1]
+    f = fine_point_matching(dp, df, E, idx, radius, model, R0, t0, W, cfg, return_aux)
+    if return_aux:
+        return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:B], fps_idx_o=idx[B:],
+                                      geo=E)
+    return f
+
+
+def _cat0(a, b):
+    """stack two (B,N,K) tensors along the batch -- a device copy, no arithmetic"""
+    a = a.contiguous()
+    b = b.contiguous()
+    out = _empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a)
+    n = a.numel()
+    _lib.call("sam6d_copy_f32", _p(a), _p(out), n, _s())
+    _lib.call("sam6d_copy_f32", _p(b), _p(out, n), b.numel(), _s())
+    return out

@@ -1,24 +1,10 @@
-import os
-import sys
-
-import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PKG = os.path.join(ROOT, "openvino-sam-6d_amd")
-for p in (ROOT, PKG, os.path.join(PKG, "pem")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
-
-GOLD = os.path.join(ROOT, "tests", "golden")
+from tests._util import ROOT, PKG, GOLD, golden  # noqa: F401  (also puts the package dirs on sys.path)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-def golden(name):
-    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
 
 
 @pytest.fixture(scope="session")

@@ -3,7 +3,7 @@ import ctypes
 import os
 import re
 
-from conftest import ROOT
+from tests._util import ROOT
 
 
 def _declared():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from tests._util import golden
 from oracle import ism_oracle as IO
 from oracle import pem_oracle as O
 from oracle import pointops as P

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from tests._util import golden
 
 pytestmark = pytest.mark.gpu
 
