@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- proposals/sec through the PEM match+SVD path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one pass of the matching path (FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching ->
+R, t, score; the region PEM/model/pose_estimation_model.py:29-55 runs after feature extraction) over one batch of
+B=32 synthetic proposals (2048 scene + 2048 template points, 1024 CAD points, random-init weights),
+with inputs resident in HBM when the timed region starts.  N>1: one process per GPU, every rank processes its own 32
+proposals (weak scaling, proposals are independent) and the ranks all-gather the 13 floats/proposal (R, t, score) over
+RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (geo_embed_kernel, fp32 MFMA), timed
+with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
+algorithm, oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "openvino-sam-6d_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+B_PER_GPU = 32
+GEO_FLOP_PER_CLOUD = 2.0 * 197 * 197 * 4 * 256 * 256  # 20.35 GFLOP: (d + 3 angular rows) x 256x256 per pair
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(sd, nprop, threads):
+    """The reference algorithm's CPU port (oracle), including the reference's dense (ns x N) compare in the weighted
+    sampling (PEM/utils/model_utils.py:277-305), on `nprop` proposals of the config-2 generator, one at a time (the
+    reference needs ~2.8 GB per proposal in that step)."""
+    from oracle import pem_oracle as O
+    from sam6d_hip import synth
+    torch.set_num_threads(threads)
+    inp = synth.config2_inputs(B=nprop, seed=1)
+    outs = []
+    t0 = time.perf_counter()
+    for i in range(nprop):
+        sl = lambda k: inp[k][i:i + 1].contiguous()
+        with torch.no_grad():
+            outs.append(O.pem_match(sl("dense_pm"), sl("dense_fm"), sl("dense_po"), sl("dense_fo"), sl("radius"), sl("model"),
+                                    sd, sl("rand"), faithful=True))
+    dt = time.perf_counter() - t0
+    R = torch.cat([o[0] for o in outs]); t = torch.cat([o[1] for o in outs]); s = torch.cat([o[2] for o in outs])
+    return nprop / dt, dt, (R, t, s), inp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-proposals", type=int, default=2, help="proposals in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import sam6d_hip
+    sam6d_hip.require_lib()
+    from sam6d_hip import pem, synth
+    from sam6d_hip.parallel import gather_poses
+
+    B = args.batch
+    sd = synth.make_pem_weights(1)
+    W = pem.PemWeights(sd, dev)
+    inp = synth.config2_inputs(B=B, seed=1 + rank)  # every rank its own shard of proposals
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    torch.cuda.synchronize()
+
+    def step():
+        R, t, s = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+        return gather_poses(R, t, s, dist) if world > 1 else (R, t, s)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    pem.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, pem.PROFILE = pem.PROFILE, None
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total = world * B * args.steps
+        ev = prof.get("geo_embed_kernel", [])
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        geo_ms = sum(ms) / max(1, len(ms))
+        achieved = (2 * B * GEO_FLOP_PER_CLOUD) / (geo_ms * 1e-3) / 1e12 if ev else None
+        res = {
+            "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
+            "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PEM batch=%d proposals/GPU, 2048 scene + 2048 model pts, 1024 CAD pts, random-init weights "
+                                   "(SURVEY 8d config 2)" % B, "proposals_per_gpu": B, "parallelism": "proposal-sharded x%d, "
+                                   "RCCL all-gather of 13 floats/proposal" % world},
+            "roofline": {"bound": "mfma", "kernel": "geo_embed_kernel (fp32 MFMA 32x32x2, 2B clouds per launch)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": None,
+                         "launch_ms": geo_ms, "launches_timed": len(ms)},
+        }
+        if args.cpu_proposals > 0 and world >= 1:
+            threads = os.cpu_count() or 1
+            v, cdt, (cR, ct, cs), cinp = cpu_baseline(sd, args.cpu_proposals, threads)
+            res["cpu_baseline"] = {"value": v, "unit": "proposals/s", "cores": threads, "kind": "port",
+                                   "sample": "%d proposals of the same generator (seed 1), one at a time, oracle/pem_oracle.py "
+                                             "with the reference's dense sampling compare; %.1f s" % (args.cpu_proposals, cdt)}
+            # pose delta of the GPU path vs the CPU port on the same proposals
+            n = args.cpu_proposals
+            g = {k: v[:n].to(dev).contiguous() for k, v in cinp.items()}
+            R, t, s = pem.pem_match(g["dense_pm"], g["dense_fm"], g["dense_po"], g["dense_fo"], g["radius"], g["model"], W, g["rand"])
+            res["pose_delta_vs_cpu"] = {"max_abs_dR": float((R.cpu() - cR).abs().max()), "max_abs_dt": float((t.cpu() - ct).abs().max()),
+                                        "max_abs_dscore": float((s.cpu() - cs).abs().max()), "proposals": n}
+            res["speedup_vs_cpu_baseline"] = res["value"] / v
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

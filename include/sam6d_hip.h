@@ -78,6 +78,12 @@ int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, fl
 int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd, const float* bd,
                         const float* Wa, const float* ba, float sigma_d, float factor_a, int angle_k, int hidden,
                         int* knn_ws, float* idx_ws, float* out, void* stream);
+/* the two halves of sam6d_geo_embedding: get_embedding_indices (PEM/model/transformer.py:306-341) -> idx_ws
+ * (B,n,n,4) = {d_idx, a_idx[0..2]}, and the sinusoid + proj_d/proj_a + max contraction (:343-363) over `pairs` rows. */
+int sam6d_geo_indices(const float* points, int B, int n, float sigma_d, float factor_a, int angle_k, int* knn_ws,
+                      float* idx_ws, void* stream);
+int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, const float* Wd, const float* bd,
+                    const float* Wa, const float* ba, int hidden, float* out, void* stream);
 
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).

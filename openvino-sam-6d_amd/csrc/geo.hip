@@ -77,8 +77,13 @@ __global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict_
   for (int r = 0; r < 3; ++r) {
     const int q = knn[bi * 3 + r];
     const float r0 = p[q * 3] - x0, r1 = p[q * 3 + 1] - x1, r2 = p[q * 3 + 2] - x2;  // reference vector
-    const float c0 = r1 * a2 - r2 * a1, c1 = r2 * a0 - r0 * a2, c2 = r0 * a1 - r1 * a0;
-    float s = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    // bit recipes of the torch-CPU kernels the reference runs (pinned by tests/golden/geo_embedding.npz; the bg point
+    // at (100,100,100) makes ref/anc long and nearly parallel, so the rounding order is visible in the result):
+    //   torch.cross       : fma(u_i, v_j, -rn(u_j * v_i))
+    //   linalg.norm(dim=3): sqrt(fma(c2,c2, fma(c1,c1, rn(c0*c0))))
+    //   sum(ref*anc, -1)  : (rn(r0*a0) + rn(r1*a1)) + rn(r2*a2)
+    const float c0 = fmaf(r1, a2, -(r2 * a1)), c1 = fmaf(r2, a0, -(r0 * a2)), c2 = fmaf(r0, a1, -(r1 * a0));
+    float s = sqrtf(fmaf(c2, c2, fmaf(c1, c1, c0 * c0)));
     float c = (r0 * a0 + r1 * a1) + r2 * a2;
     s = fmaxf(s, 1e-8f);
     c = fminf(fmaxf(c, -1.0f + 1e-8f), 1.0f - 1e-8f);  // == clamp(-1, 1) in fp32
@@ -185,22 +190,42 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
   }
 }
 
-extern "C" int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd,
-                                   const float* bd, const float* Wa, const float* ba, float sigma_d, float factor_a,
-                                   int angle_k, int hidden, int* knn_ws, float* idx_ws, float* out, void* stream) {
-  SAM6D_REQUIRE(points && div_term && Wd && bd && Wa && ba && knn_ws && idx_ws && out, "geo_embedding: null pointer");
+static int geo_check(int B, int n, int angle_k, int hidden) {
   SAM6D_REQUIRE(angle_k == 3 && hidden == 256, "geo_embedding: only angle_k=3, hidden_dim=256 (PEM/config/base.yaml:26-31)");
   SAM6D_REQUIRE(B >= 0 && n >= 4 && n <= 256, "geo_embedding: need 4 <= n <= 256 (got %d)", n);
-  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embedding: idx_ws/weights must be 16-byte aligned");
+  return 0;
+}
+
+extern "C" int sam6d_geo_indices(const float* points, int B, int n, float sigma_d, float factor_a, int angle_k, int* knn_ws,
+                                 float* idx_ws, void* stream) {
+  SAM6D_REQUIRE(points && knn_ws && idx_ws, "geo_indices: null pointer");
+  if (int rc = geo_check(B, n, angle_k, 256)) return rc;
+  SAM6D_REQUIRE((((size_t)idx_ws) & 15) == 0, "geo_indices: idx_ws must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)B * n, pairs = rows * n;
   hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, points, n, angle_k, knn_ws, rows);
-  SAM6D_LAUNCH_CHECK_CONT("geo_embedding(knn)");
+  SAM6D_LAUNCH_CHECK_CONT("geo_indices(knn)");
   hipLaunchKernelGGL(geo_index_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, points, knn_ws, n, sigma_d,
                      factor_a, reinterpret_cast<float4*>(idx_ws), pairs);
-  SAM6D_LAUNCH_CHECK_CONT("geo_embedding(indices)");
-  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, s,
+  SAM6D_LAUNCH_CHECK("geo_indices");
+}
+
+extern "C" int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, const float* Wd, const float* bd,
+                               const float* Wa, const float* ba, int hidden, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && Wd && bd && Wa && ba && out, "geo_embed: null pointer");
+  SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed: hidden_dim must be 256");
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embed: idx_ws/weights must be 16-byte aligned");
+  if (pairs == 0) return 0;
+  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs);
-  SAM6D_LAUNCH_CHECK("geo_embedding");
+  SAM6D_LAUNCH_CHECK("geo_embed");
+}
+
+extern "C" int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd,
+                                   const float* bd, const float* Wa, const float* ba, float sigma_d, float factor_a,
+                                   int angle_k, int hidden, int* knn_ws, float* idx_ws, float* out, void* stream) {
+  if (int rc = geo_check(B, n, angle_k, hidden)) return rc;
+  if (int rc = sam6d_geo_indices(points, B, n, sigma_d, factor_a, angle_k, knn_ws, idx_ws, stream)) return rc;
+  return sam6d_geo_embed(idx_ws, (long)B * n * n, div_term, Wd, bd, Wa, ba, hidden, out, stream);
 }

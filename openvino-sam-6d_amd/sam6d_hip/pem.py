@@ -143,6 +143,27 @@ def _post_attention(hidden, x2d, L):
     return layernorm(linear(h, L["sq"], residual=y), L["n2"])
 
 
+# optional profiling hook: bench.py sets PROFILE = {} and reads back lists of (start, end) torch.cuda.Event pairs per
+# kernel name.  Events are recorded on the launch stream and cost nothing when PROFILE is None.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, self.b))
+
+
 def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     """points_bg (B,n,3) with the bg point prepended -> (B,n,n,256)   (PEM/model/transformer.py:343-363)."""
     B, n, _ = points_bg.shape
@@ -150,8 +171,10 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     knn = _empty((B, n, angle_k), points_bg, torch.int32)
     idx = _empty((B, n, n, 4), points_bg)
     factor_a = 180.0 / (sigma_a * math.pi)
-    _lib.call("sam6d_geo_embedding", _p(points_bg), B, n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
-              _p(W.geo_a.b), float(sigma_d), float(factor_a), angle_k, C, _p(knn), _p(idx), _p(out), _s())
+    _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
+    with _Timed("geo_embed_kernel"):
+        _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
+                  _p(W.geo_a.b), C, _p(out), _s())
     return out
 
 

@@ -96,9 +96,12 @@ def test_geo_embedding_golden(dev, W, sd):
     pts = _t(g["pts"])
     out = pem.geo_embedding(pts.to(dev), W)
     rows = g["rows"]
-    _close(out[:, rows], g["out_rows"], 3e-5, "geo embedding vs reference rows")
+    # 6e-5: pairs with the bg point have d_idx ~ 866 where one fp32 ulp is 6.1e-5, and torch's vectorised CPU sqrt is
+    # not correctly rounded on 0.6 % of the entries (see test_geo_indices_and_knn); everything else agrees to ~8e-6
+    _close(out[:, rows], g["out_rows"], 6e-5, "geo embedding vs reference rows")
+    _close(out[:, rows][:, 1:], g["out_rows"][:, 1:], 2e-5, "geo embedding vs reference rows (non-bg centres)")
     full = O.geo_embedding(pts, sd)
-    _close(out, full, 3e-5, "geo embedding vs oracle (all pairs)")
+    _close(out, full, 6e-5, "geo embedding vs oracle (all pairs)")
 
 
 def test_geo_indices_and_knn(dev, W):
@@ -114,8 +117,16 @@ def test_geo_indices_and_knn(dev, W):
               W.geo_a.w.data_ptr(), W.geo_a.b.data_ptr(), 0.2, 180.0 / (15 * math.pi), 3, 256, knn.data_ptr(), idx.data_ptr(),
               out.data_ptr(), pem._s())
     assert np.array_equal(knn.cpu().numpy(), g["knn"].astype(np.int32))
-    assert np.array_equal(idx[..., 0].cpu().numpy(), g["d_idx"])
-    _close(idx[..., 1:], g["a_idx"], 3e-5, "a_idx")
+    # d_idx = sqrt(pd) / 0.2: the device result is the correctly rounded one (checked here in fp64); the reference's
+    # torch-CPU sqrt is 1 ulp low on ~0.6 % of the entries, so the golden tensor is matched to <= 1 ulp, >= 99 % exact
+    from oracle import pem_oracle as O
+    pd = O.pairwise_distance(_t(g["pts"]), _t(g["pts"])).numpy()
+    cr = (np.sqrt(pd.astype(np.float64)).astype(np.float32).astype(np.float64) / np.float64(np.float32(0.2))).astype(np.float32)
+    d = idx[..., 0].cpu().numpy()
+    assert np.array_equal(d, cr), "d_idx must be the correctly rounded sqrt and quotient of the bit-exact squared distance"
+    ulp = np.abs(d.view(np.int32).astype(np.int64) - g["d_idx"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp == 0).mean() > 0.99
+    _close(idx[..., 1:], g["a_idx"], 5e-6, "a_idx")
 
 
 # -------------------------------------------------------------------------------------------------- transformer
@@ -190,25 +201,63 @@ def test_feature_similarity_golden(dev):
 
 # ------------------------------------------------------------------------------------------------------- poses
 def test_coarse_rt_golden(dev):
+    """Known-answer scene: everything, including every sampled index, matches the reference and the ground truth."""
     from sam6d_hip import pem
     g = golden("coarse_rt")
     p1, p2, model, u = (_t(g[k]).to(dev) for k in ("p1", "p2", "model", "u"))
     radius = torch.ones(2, device=dev)
-    for tag in ("", "2"):
-        att = _t(g["att" + tag]).to(dev)
-        R, t, aux = pem.compute_coarse_Rt(att, p1, p2, model, radius, u, return_aux=True)
-        assert np.array_equal(aux["w1"].cpu().numpy(), g["w1" + ("_2" if tag else "")]), "foreground mask"
-        idx = aux["idx"].cpu().numpy()
-        same = (idx == g["idx" + tag]).mean()
-        # sampled hypothesis indices: exact up to ulp differences of expf/powf between libm and the device library
-        assert same >= 0.995, "sampled indices agree on %.4f" % same
-        if tag == "":
-            assert same == 1.0, "peaky known-answer scene must sample identically (got %.5f)" % same
-        _close(R, g["R" + tag], 1e-4, "coarse R" + tag)
-        _close(t, g["t" + tag], 1e-4, "coarse t" + tag)
-    R, t = pem.compute_coarse_Rt(_t(g["att"]).to(dev), p1, p2, model, radius, u)
-    _close(R, g["R_gt"], 1e-4, "coarse KAT R vs ground truth")
-    _close(t, g["t_gt"], 1e-4, "coarse KAT t vs ground truth")
+    att = _t(g["att"]).to(dev)
+    R, t, aux = pem.compute_coarse_Rt(att, p1, p2, model, radius, u, return_aux=True)
+    assert np.array_equal(aux["w1"].cpu().numpy(), g["w1"]), "foreground mask"
+    assert np.array_equal(aux["idx"].cpu().numpy(), g["idx"]), "sampled hypothesis indices (bit-exact)"
+    assert set(aux["top"][0].tolist()) == set(g["top"][0].tolist())
+    _close(aux["dis"], g["dis"], 1e-5, "hypothesis residuals")
+    _close(R, g["R"], 1e-4, "coarse R"); _close(t, g["t"], 1e-4, "coarse t")
+    _close(R, g["R_gt"], 1e-4, "coarse KAT R vs ground truth"); _close(t, g["t_gt"], 1e-4, "coarse KAT t vs ground truth")
+
+
+def test_coarse_rt_flat_attention(dev):
+    """Structure-less attention (what random-init weights produce).  Here ~10 % of the sampled triples repeat a point
+    (rank-1 correlation matrix): the reference's rotation for those is whatever LAPACK's sgesdd makes of rounding noise
+    (SURVEY 7 'hard parts'), so they are compared for finiteness only; every well-posed hypothesis must agree."""
+    from sam6d_hip import pem
+    from oracle import pem_oracle as O
+    g = golden("coarse_rt")
+    cpu = {k: _t(g[k]) for k in ("p1", "p2", "model", "u", "att2")}
+    p1, p2, model, u, att = (cpu[k].to(dev) for k in ("p1", "p2", "model", "u", "att2"))
+    radius = torch.ones(2, device=dev)
+    R, t, aux = pem.compute_coarse_Rt(att, p1, p2, model, radius, u, return_aux=True)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(aux["Rs"]).all()
+    assert np.array_equal(aux["w1"].cpu().numpy(), g["w1_2"])
+    ref_idx = _t(g["idx2"]).long()
+    gidx = aux["idx"].cpu().long()
+    same_frac = (gidx == ref_idx).float().mean().item()
+    assert same_frac >= 0.995, "sampled indices agree on %.5f (expf/powf ulp differences move a few thresholds)" % same_frac
+    Rs_o, ts_o, dis_o = O.coarse_hypotheses(ref_idx, cpu["p1"], cpu["p2"], 6000)
+    tri1 = (ref_idx // 196).reshape(2, 6000, 3); tri2 = (ref_idx % 196).reshape(2, 6000, 3)
+    distinct = lambda x: (x[..., 0] != x[..., 1]) & (x[..., 0] != x[..., 2]) & (x[..., 1] != x[..., 2])
+    same = (gidx == ref_idx).reshape(2, 6000, 3).all(-1)
+    wellposed = distinct(tri1) & distinct(tri2) & same
+    # conditioning of the remaining 3-point problems (fp64): drop near-collinear triples
+    a = torch.gather(cpu["p2"], 1, (ref_idx % 196).unsqueeze(2).expand(2, 18000, 3)).reshape(2, 6000, 3, 3).double()
+    bq = torch.gather(cpu["p1"], 1, (ref_idx // 196).unsqueeze(2).expand(2, 18000, 3)).reshape(2, 6000, 3, 3).double()
+    Hm = (a - a.mean(2, keepdim=True)).transpose(2, 3) @ (bq - bq.mean(2, keepdim=True))
+    sv = torch.linalg.svdvals(Hm)
+    wellposed &= (sv[..., 1] / sv[..., 0]) > 0.05
+    assert wellposed.float().mean() > 0.5
+    Rs = aux["Rs"].cpu().reshape(2, 6000, 3, 3); ts = aux["ts"].cpu().reshape(2, 6000, 1, 3)
+    _close(Rs[wellposed], Rs_o[wellposed], 1e-4, "well-posed hypothesis rotations")
+    _close(ts[wellposed], ts_o[wellposed], 1e-4, "well-posed hypothesis translations")
+    _close(aux["dis"].cpu()[same], dis_o[same], 2e-6, "hypothesis residuals (all hypotheses with identical samples)")
+    # scores of well-posed hypotheses present in both top-300 sets
+    for b in range(2):
+        sg = dict(zip(g["top2"][b].tolist(), g["scores2"][b].tolist()))
+        sd_ = dict(zip(aux["top"][b].tolist(), aux["scores"][b].tolist()))
+        common = [h for h in sg if h in sd_ and bool(wellposed[b, h])]
+        assert len(common) > 100
+        rel = max(abs(sg[h] - sd_[h]) / sg[h] for h in common)
+        assert rel < 1e-4, "hypothesis scores, rel diff %.2e" % rel
+        assert len(set(sg) & set(sd_)) >= 295, "top-300 sets"
 
 
 def test_weighted_sample_bit_exact(dev):
@@ -223,8 +272,9 @@ def test_weighted_sample_bit_exact(dev):
     want = O.weighted_sampling(w, u)
     cum = torch.empty(3, 38416, device=dev)
     idx = torch.empty(3, 18000, dtype=torch.int32, device=dev)
-    _lib.call("sam6d_weighted_sample", w.to(dev).data_ptr(), u.to(dev).data_ptr(), 3, 38416, 18000, cum.data_ptr(),
-              idx.data_ptr(), pem._s())
+    wd, ud = w.to(dev), u.to(dev)  # keep the device tensors alive across the launch
+    _lib.call("sam6d_weighted_sample", wd.data_ptr(), ud.data_ptr(), 3, 38416, 18000, cum.data_ptr(), idx.data_ptr(), pem._s())
+    torch.cuda.synchronize()
     assert torch.equal(idx.cpu().long(), want)
     assert (idx[2] == 0).all()
 
@@ -235,7 +285,9 @@ def test_select_smallest_matches_topk_set(dev):
     d = torch.rand(4, 6000, generator=gen)
     d[0, 100:140] = 0.0  # exact ties
     sel = torch.empty(4, 300, dtype=torch.int32, device=dev)
-    _lib.call("sam6d_select_smallest", d.to(dev).data_ptr(), 4, 6000, 300, sel.data_ptr(), pem._s())
+    dd = d.to(dev)
+    _lib.call("sam6d_select_smallest", dd.data_ptr(), 4, 6000, 300, sel.data_ptr(), pem._s())
+    torch.cuda.synchronize()
     s = sel.cpu().long()
     vals = torch.gather(d, 1, s)
     assert (vals[:, 1:] >= vals[:, :-1]).all(), "ascending order"
