@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict
   W += (size_t)bz * sW;
   C += (size_t)bz * sC;
   if (residual) residual += (size_t)bz * sR;
-  const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+  const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   f32x16 acc[2][2];
@@ -131,8 +131,8 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
   SAM6D_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (ReLU)");
   SAM6D_REQUIRE(batch <= 65535, "gemm_nt: batch must be <= 65535");
   if (M == 0 || N == 0 || batch == 0) return 0;
-  dim3 grid(cdiv(N, GM_BN), cdiv(M, GM_BM), batch);
-  SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: M too large for one launch (%d)", M);
+  dim3 grid(cdiv(M, GM_BM), cdiv(N, GM_BN), batch);  // M tiles on x (2^31 limit): the PE MLP has 8.4 M rows
+  SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
   hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C, M, N, K,
                      lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
   SAM6D_LAUNCH_CHECK("gemm_nt");
