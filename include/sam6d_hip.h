@@ -152,6 +152,33 @@ int sam6d_weighted_procrustes(const float* src, const float* ref, const float* w
 int sam6d_fine_score(const float* pts1, const float* R, float* t, const float* model, const float* radius,
                      const int* label1, int B, int N, int P, float dis_thres, float* cnt_ws, float* score, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * B3: ISM template scoring (Instance_Segmentation_Model methods + model.loss classes).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* replaces PairwiseSimilarity.forward (ISM/model/loss.py:27-44): query (Nq,D), ref (No,Nt,D) -> scores (Nq,No,Nt) in [0,1]. */
+int sam6d_ism_cosine(const float* query, const float* ref, int Nq, int No, int Nt, int D, float* scores, void* stream);
+/* replaces the tail of compute_semantic_score + best_template_pose (ISM/model/detector.py:198-207, 265-296):
+ * per query the aggregated score (mode 0 avg_5 / 1 mean / 2 max), arg-max object and its best template; `sel` = ascending
+ * indices of the queries with score > thresh, *nsel their count (device int). */
+int sam6d_ism_semantic(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem, int* obj, int* best,
+                       int* sel, int* nsel, void* stream);
+/* replaces compute_straight + compute_visible_ratio reductions (ISM/model/loss.py:52-76) over sim (Ns,P,P). */
+int sam6d_ism_patch_scores(const float* sim, const float* q_appe, int Ns, int P, int D, float thred, float* appe, float* vis,
+                           void* stream);
+/* replaces project_template_to_image + Calculate_the_query_translation (ISM/model/detector.py:209-246,
+ * ISM/utils/trimesh_utils.py:77-105): masks (Ns,H,W) f32, depth (H,W) i32, K (3,3) f64, poses (Nt,4,4) f32,
+ * pointcloud (No,Npc,3) -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3); part_ws (Ns*64*4) f64 scratch. */
+int sam6d_ism_project(const float* masks, const int* depth, const double* K, double depth_scale, const float* poses,
+                      const float* pointcloud, const int* best, const int* obj, int Ns, int H, int W, int Npc,
+                      double* part_ws, int* image_vu, int* xyxy, float* translate, void* stream);
+/* replaces compute_iou (ISM/utils/bbox_utils.py:197-222): boxes (Ns,4) int64; *all_positive = 0 when any pair has a
+ * non-positive overlap (the reference then returns the scalar 0.0). */
+int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, float* iou, int* all_positive, void* stream);
+/* final score (ISM/model/detector.py:384): (sem[sel] + appe + geo*vis) / (2 + vis); geo NULL = the scalar-0.0 IoU case. */
+int sam6d_ism_final_score(const float* sem, const float* appe, const float* geo, const float* vis, const int* sel, int Ns,
+                          float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

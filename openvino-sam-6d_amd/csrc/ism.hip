@@ -1,0 +1,368 @@
+// ISM template scoring for gfx950:
+//   PairwiseSimilarity / compute_semantic_score / best_template_pose   ISM/model/loss.py:27-44, ISM/model/detector.py:198-207,260-296
+//   compute_straight (appearance) / compute_visible_ratio             ISM/model/loss.py:52-76, detector.py:298-322
+//   project_template_to_image / Calculate_the_query_translation       detector.py:209-246, ISM/utils/trimesh_utils.py:77-105
+//   compute_iou                                                       ISM/utils/bbox_utils.py:197-222
+// All HBM-bound reductions (wave butterflies, coalesced 16-byte lanes); the 256x256x1024 patch-similarity contraction
+// runs on the matrix cores through gemm_nt.
+#include "common.h"
+#include "../../include/sam6d_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// cosine similarity of every query descriptor with every template descriptor, clamped to [0,1].
+// The reference L2-normalises both sides and then calls F.cosine_similarity (which divides by the norms again,
+// eps 1e-8); both steps are reproduced.  One wave per (query, template) pair.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ism_cosine_kernel(const float* __restrict__ q, const float* __restrict__ ref, int D,
+                                                         int NT, long total, float* __restrict__ out) {
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over Nq * (No*Nt)
+  if (w >= total) return;
+  const int lane = threadIdx.x & 63;
+  const long iq = w / NT;
+  const long it = w % NT;
+  const float* a = q + iq * D;
+  const float* b = ref + it * D;
+  float sa = 0.f, sb = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(a + c);
+    const float4 y = *reinterpret_cast<const float4*>(b + c);
+    sa += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    sb += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+  }
+  const float na = fmaxf(sqrtf(wave_sum(sa)), 1e-12f), nb = fmaxf(sqrtf(wave_sum(sb)), 1e-12f);  // F.normalize
+  float dot = 0.f, s2a = 0.f, s2b = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(a + c);
+    const float4 y = *reinterpret_cast<const float4*>(b + c);
+    const float x0 = x.x / na, x1 = x.y / na, x2 = x.z / na, x3 = x.w / na;
+    const float y0 = y.x / nb, y1 = y.y / nb, y2 = y.z / nb, y3 = y.w / nb;
+    dot += (x0 * y0 + x1 * y1) + (x2 * y2 + x3 * y3);
+    s2a += (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+    s2b += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3);
+  }
+  dot = wave_sum(dot);
+  s2a = wave_sum(s2a);
+  s2b = wave_sum(s2b);
+  if (lane == 0) {
+    const float c = dot / (fmaxf(sqrtf(s2a), 1e-8f) * fmaxf(sqrtf(s2b), 1e-8f));  // F.cosine_similarity
+    out[w] = fminf(fmaxf(c, 0.f), 1.f);
+  }
+}
+
+extern "C" int sam6d_ism_cosine(const float* query, const float* ref, int Nq, int No, int Nt, int D, float* scores,
+                                void* stream) {
+  SAM6D_REQUIRE(query && ref && scores, "ism_cosine: null pointer");
+  SAM6D_REQUIRE(Nq >= 0 && No > 0 && Nt > 0 && D > 0 && (D & 3) == 0, "ism_cosine: bad sizes (D %% 4 == 0)");
+  const long total = (long)Nq * No * Nt;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(ism_cosine_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, query, ref, D,
+                     No * Nt, total, scores);
+  SAM6D_LAUNCH_CHECK("ism_cosine");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per query: aggregate template scores per object (avg_5 = mean of the 5 largest / mean / max), argmax object,
+// best template of that object (first maximum).  One wave per query; Nt <= 64*4.
+// mode: 0 = avg_5, 1 = mean, 2 = max   (detector.py:265-277)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ism_semantic_kernel(const float* __restrict__ scores, int No, int Nt, int mode,
+                                                          float* __restrict__ sem, int* __restrict__ obj, int* __restrict__ best) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  float bscore = -INFINITY;
+  int bobj = 0, bbest = 0;
+  for (int o = 0; o < No; ++o) {
+    const float* s = scores + ((size_t)q * No + o) * Nt;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (lane + 64 * u < Nt) ? s[lane + 64 * u] : -INFINITY;
+    // arg-max template (first maximum)
+    float mv = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v[u] > mv) { mv = v[u]; mi = lane + 64 * u; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const float ov = __shfl_xor(mv, d, 64);
+      const int oi = __shfl_xor(mi, d, 64);
+      if (ov > mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; }
+    }
+    float agg;
+    if (mode == 2) {
+      agg = mv;
+    } else if (mode == 1) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t += (lane + 64 * u < Nt) ? v[u] : 0.f;
+      agg = wave_sum(t) / (float)Nt;
+    } else {  // mean of the 5 largest, summed in descending order like torch.topk(...)[0].mean()
+      float t = 0.f;
+      const int k = Nt < 5 ? Nt : 5;
+      for (int r = 0; r < k; ++r) {
+        float lm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        const float gm = wave_max(lm);
+        t += gm;
+        // remove ONE occurrence of gm (lowest lane holding it)
+        const unsigned long long has = __ballot(lm == gm);
+        if (lane == (int)(__ffsll((long long)has) - 1)) {
+          bool done = false;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (!done && v[u] == gm) { v[u] = -INFINITY; done = true; }
+        }
+      }
+      agg = t / (float)k;
+    }
+    if (agg > bscore) { bscore = agg; bobj = o; bbest = mi; }
+  }
+  if (lane == 0) {
+    sem[q] = bscore;
+    obj[q] = bobj;
+    best[q] = bbest;
+  }
+}
+
+// ordered compaction of the queries whose score exceeds the confidence threshold (detector.py:284-287); Nq <= 1024.
+__global__ __launch_bounds__(1024) void ism_select_kernel(const float* __restrict__ sem, int Nq, float thresh,
+                                                          int* __restrict__ sel, int* __restrict__ nsel) {
+  __shared__ int wcnt[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool keep = (t < Nq) && (sem[t] > thresh);
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wcnt[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wcnt[w];
+  if (keep) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+  if (t == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += wcnt[w];
+    *nsel = tot;
+  }
+}
+
+extern "C" int sam6d_ism_semantic(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem, int* obj,
+                                  int* best, int* sel, int* nsel, void* stream) {
+  SAM6D_REQUIRE(scores && sem && obj && best && sel && nsel, "ism_semantic: null pointer");
+  SAM6D_REQUIRE(Nq >= 0 && Nq <= 1024 && No > 0 && Nt > 0 && Nt <= 256 && mode >= 0 && mode <= 2,
+                "ism_semantic: need Nq <= 1024, Nt <= 256, mode in {0 avg_5, 1 mean, 2 max}");
+  hipStream_t s = (hipStream_t)stream;
+  if (Nq > 0) hipLaunchKernelGGL(ism_semantic_kernel, dim3(Nq), dim3(64), 0, s, scores, No, Nt, mode, sem, obj, best);
+  hipLaunchKernelGGL(ism_select_kernel, dim3(1), dim3(1024), 0, s, sem, Nq, thresh, sel, nsel);
+  SAM6D_LAUNCH_CHECK("ism_semantic");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// patch-similarity reductions over sim (Ns, P, P) = q_appe @ ref_appe^T  (rows: query patches, cols: template patches)
+//   appearance  = clamp( sum_rows max_cols sim / (count_nonzero(rowsum(q_appe)) + 1e-6), 0, 1 )      loss.py:52-62
+//   visible     = count(colmax > thr and colmax != 0) / (count_nonzero(colmax) + 1e-6), colmax = max_rows sim   :64-76
+// One workgroup per proposal.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ism_patch_scores_kernel(const float* __restrict__ sim, const float* __restrict__ q_appe,
+                                                               int P, int D, float thr, float* __restrict__ appe,
+                                                               float* __restrict__ vis) {
+  __shared__ float red[3][4];
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* S = sim + (size_t)i * P * P;
+  // row maxima (one wave per row, strided) and the query-patch occupancy
+  float rsum = 0.f, nz = 0.f;
+  for (int r = wave; r < P; r += 4) {
+    float m = -INFINITY;
+    for (int c = lane; c < P; c += 64) m = fmaxf(m, S[(size_t)r * P + c]);
+    m = wave_max(m);
+    const float* qr = q_appe + ((size_t)i * P + r) * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(qr + c);
+      s += (x.x + x.y) + (x.z + x.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      rsum += m;
+      nz += (s != 0.f) ? 1.f : 0.f;
+    }
+  }
+  // column maxima: thread per column
+  float cv = 0.f, cn = 0.f;
+  for (int c = t; c < P; c += 256) {
+    float m = -INFINITY;
+    for (int r = 0; r < P; ++r) m = fmaxf(m, S[(size_t)r * P + c]);
+    cn += (m != 0.f) ? 1.f : 0.f;
+    cv += (m > thr && m != 0.f) ? 1.f : 0.f;
+  }
+  cv = wave_sum(cv);
+  cn = wave_sum(cn);
+  if (lane == 0) {
+    red[0][wave] = rsum;
+    red[1][wave] = nz;
+    red[2][wave] = cv;
+  }
+  __shared__ float red2[4];
+  if (lane == 0) red2[wave] = cn;
+  __syncthreads();
+  if (t == 0) {
+    const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float n = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float v = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float vn = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    appe[i] = fminf(fmaxf(a / (n + 1e-6f), 0.f), 1.f);
+    vis[i] = v / (vn + 1e-6f);
+  }
+}
+
+extern "C" int sam6d_ism_patch_scores(const float* sim, const float* q_appe, int Ns, int P, int D, float thred, float* appe,
+                                      float* vis, void* stream) {
+  SAM6D_REQUIRE(sim && q_appe && appe && vis && Ns >= 0 && P > 0 && D > 0 && (D & 3) == 0, "ism_patch_scores: bad arguments");
+  if (Ns == 0) return 0;
+  hipLaunchKernelGGL(ism_patch_scores_kernel, dim3(Ns), dim3(256), 0, (hipStream_t)stream, sim, q_appe, P, D, thred, appe, vis);
+  SAM6D_LAUNCH_CHECK("ism_patch_scores");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Query translation = mean back-projected masked depth (detector.py:234-246, trimesh_utils.py:77-105), then template
+// point cloud -> image (detector.py:209-232).  The reference's caller hands K and depth_scale over as float64
+// (ISM/run_inference_custom.py:87-94), which makes its whole translation computation float64 until the final
+// .to(float32) (detector.py:246); the kernel does the same: per-pixel terms and sums in double, K in double.
+// The projection uses K cast to float32, as detector.py:225 does.
+// ---------------------------------------------------------------------------------------------------------------
+#define ISM_TCH 64  // pixel chunks per proposal
+__global__ __launch_bounds__(256) void ism_translate_partial_kernel(const float* __restrict__ masks, const int* __restrict__ depth,
+                                                                    const double* __restrict__ K, double scale, int H, int Wd,
+                                                                    double* __restrict__ part) {
+  __shared__ double red[4][4];
+  const int i = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
+  const long npx = (long)H * Wd;
+  const long per = (npx + ISM_TCH - 1) / ISM_TCH;
+  const long p0 = ch * per, p1 = min(npx, p0 + per);
+  const float* m = masks + (size_t)i * npx;
+  const double cx = K[2], fx = K[0], cy = K[5], fy = K[4];
+  double sx = 0, sy = 0, sz = 0, sn = 0;
+  for (long p = p0 + t; p < p1; p += 256) {
+    const double md = (double)(m[p] * (float)depth[p]);  // mask * depth (exact: 0/1 times an integer < 2^24)
+    const double Z = md * scale / 1000.0;
+    if (Z > 0.0) {
+      const int u = (int)(p % Wd), v = (int)(p / Wd);
+      sx += ((double)u - cx) * Z / fx;
+      sy += ((double)v - cy) * Z / fy;
+      sz += Z;
+      sn += 1.0;
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); sn = wave_sum(sn);
+  if ((t & 63) == 0) { red[0][t >> 6] = sx; red[1][t >> 6] = sy; red[2][t >> 6] = sz; red[3][t >> 6] = sn; }
+  __syncthreads();
+  if (t < 4) part[((size_t)i * ISM_TCH + ch) * 4 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+}
+
+// one workgroup per proposal: finish the translation, pose the cloud, project, truncate, clamp, bounding box
+__global__ __launch_bounds__(256) void ism_project_kernel(const double* __restrict__ part, const float* __restrict__ poses,
+                                                          const float* __restrict__ pc, const int* __restrict__ best,
+                                                          const int* __restrict__ obj, const double* __restrict__ Kd, int Npc, int H,
+                                                          int Wd, int* __restrict__ vu, int* __restrict__ xyxy,
+                                                          float* __restrict__ translate) {
+  __shared__ float tr[3];
+  float K[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) K[e] = (float)Kd[e];
+  __shared__ int bb[4][4];
+  const int i = blockIdx.x, t = threadIdx.x;
+  if (t < 3) {
+    double s = 0, n = 0;
+    for (int c = 0; c < ISM_TCH; ++c) {
+      s += part[((size_t)i * ISM_TCH + c) * 4 + t];
+      n += part[((size_t)i * ISM_TCH + c) * 4 + 3];
+    }
+    tr[t] = (float)(s / (n + 1e-8));
+    translate[i * 3 + t] = tr[t];
+  }
+  __syncthreads();
+  const float* R = poses + (size_t)best[i] * 16;  // (4,4) row-major, rotation = [0:3,0:3]
+  const float* P = pc + (size_t)obj[i] * Npc * 3;
+  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -0x7fffffff, y1 = -0x7fffffff;
+  for (int k = t; k < Npc; k += 256) {
+    const float a = P[k * 3], b = P[k * 3 + 1], c = P[k * 3 + 2];
+    // posed = R @ p (torch matmul K=3 chain) + translate
+    const float X = fmaf(R[2], c, fmaf(R[1], b, R[0] * a)) + tr[0];
+    const float Y = fmaf(R[6], c, fmaf(R[5], b, R[4] * a)) + tr[1];
+    const float Z = fmaf(R[10], c, fmaf(R[9], b, R[8] * a)) + tr[2];
+    // homogeneous image point K @ posed, divided by its last component
+    const float hx = fmaf(K[2], Z, fmaf(K[1], Y, K[0] * X));
+    const float hy = fmaf(K[5], Z, fmaf(K[4], Y, K[3] * X));
+    const float hz = fmaf(K[8], Z, fmaf(K[7], Y, K[6] * X));
+    int px = (int)(hx / hz), py = (int)(hy / hz);  // .to(torch.int): truncation toward zero
+    px = min(max(px, 0), Wd - 1);
+    py = min(max(py, 0), H - 1);
+    vu[((size_t)i * Npc + k) * 2] = px;
+    vu[((size_t)i * Npc + k) * 2 + 1] = py;
+    x0 = min(x0, px); y0 = min(y0, py); x1 = max(x1, px); y1 = max(y1, py);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, d, 64)); y0 = min(y0, __shfl_xor(y0, d, 64));
+    x1 = max(x1, __shfl_xor(x1, d, 64)); y1 = max(y1, __shfl_xor(y1, d, 64));
+  }
+  if ((t & 63) == 0) { bb[0][t >> 6] = x0; bb[1][t >> 6] = y0; bb[2][t >> 6] = x1; bb[3][t >> 6] = y1; }
+  __syncthreads();
+  if (t == 0) {
+    xyxy[i * 4 + 0] = min(min(bb[0][0], bb[0][1]), min(bb[0][2], bb[0][3]));
+    xyxy[i * 4 + 1] = min(min(bb[1][0], bb[1][1]), min(bb[1][2], bb[1][3]));
+    xyxy[i * 4 + 2] = max(max(bb[2][0], bb[2][1]), max(bb[2][2], bb[2][3]));
+    xyxy[i * 4 + 3] = max(max(bb[3][0], bb[3][1]), max(bb[3][2], bb[3][3]));
+  }
+}
+
+extern "C" int sam6d_ism_project(const float* masks, const int* depth, const double* K, double depth_scale, const float* poses,
+                                 const float* pointcloud, const int* best, const int* obj, int Ns, int H, int W, int Npc,
+                                 double* part_ws, int* image_vu, int* xyxy, float* translate, void* stream) {
+  SAM6D_REQUIRE(masks && depth && K && poses && pointcloud && best && obj && part_ws && image_vu && xyxy && translate,
+                "ism_project: null pointer");
+  SAM6D_REQUIRE(Ns >= 0 && Ns <= 65535 && H > 0 && W > 0 && Npc > 0, "ism_project: bad sizes");
+  if (Ns == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ism_translate_partial_kernel, dim3(ISM_TCH, Ns), dim3(256), 0, s, masks, depth, K, depth_scale, H, W, part_ws);
+  hipLaunchKernelGGL(ism_project_kernel, dim3(Ns), dim3(256), 0, s, part_ws, poses, pointcloud, best, obj, K, Npc, H, W, image_vu,
+                     xyxy, translate);
+  SAM6D_LAUNCH_CHECK("ism_project");
+}
+
+// IoU of the projected-template box with the proposal box (bbox_utils.py:197-222), integer arithmetic as in the
+// reference; `all_positive` (device int, pre-set to 1 here) is cleared when any pair has a non-positive overlap --
+// the caller turns that into the reference's scalar-0.0 result (:214-220).  final = (sem + appe + iou*vis)/(2 + vis).
+__global__ void ism_iou_kernel(const int* __restrict__ a, const long long* __restrict__ b, int Ns, float* __restrict__ iou,
+                               int* __restrict__ all_positive) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Ns) return;
+  const long long ax0 = a[i * 4], ay0 = a[i * 4 + 1], ax1 = a[i * 4 + 2], ay1 = a[i * 4 + 3];
+  const long long bx0 = b[i * 4], by0 = b[i * 4 + 1], bx1 = b[i * 4 + 2], by1 = b[i * 4 + 3];
+  const long long w = min(ax1, bx1) - max(ax0, bx0), h = min(ay1, by1) - max(ay0, by0);
+  if (!(w > 0 && h > 0)) atomicAnd(all_positive, 0);
+  const long long inter = w * h, aa = (ax1 - ax0) * (ay1 - ay0), ab = (bx1 - bx0) * (by1 - by0);
+  iou[i] = (float)inter / (float)(aa + ab - inter);
+}
+
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
+extern "C" int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, float* iou, int* all_positive, void* stream) {
+  SAM6D_REQUIRE(xyxy && boxes && iou && all_positive && Ns >= 0, "ism_iou: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, all_positive, 1);
+  if (Ns > 0) hipLaunchKernelGGL(ism_iou_kernel, dim3(cdiv(Ns, 256)), dim3(256), 0, s, xyxy, boxes, Ns, iou, all_positive);
+  SAM6D_LAUNCH_CHECK("ism_iou");
+}
+
+__global__ void ism_final_kernel(const float* __restrict__ sem, const float* __restrict__ appe, const float* __restrict__ geo,
+                                 const float* __restrict__ vis, const int* __restrict__ sel, int Ns, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Ns) return;
+  const float g = geo ? geo[i] : 0.f;  // geo == NULL: the scalar-0.0 IoU quirk
+  const float s = sem[sel ? sel[i] : i];
+  out[i] = ((s + appe[i]) + g * vis[i]) / ((1.f + 1.f) + vis[i]);
+}
+
+extern "C" int sam6d_ism_final_score(const float* sem, const float* appe, const float* geo, const float* vis, const int* sel,
+                                     int Ns, float* out, void* stream) {
+  SAM6D_REQUIRE(sem && appe && vis && out && Ns >= 0, "ism_final_score: bad arguments");
+  if (Ns == 0) return 0;
+  hipLaunchKernelGGL(ism_final_kernel, dim3(cdiv(Ns, 256)), dim3(256), 0, (hipStream_t)stream, sem, appe, geo, vis, sel, Ns, out);
+  SAM6D_LAUNCH_CHECK("ism_final_score");
+}

@@ -47,6 +47,12 @@ SIGNATURES = {
     "sam6d_score_select_hypotheses": [c_p] * 7 + [c_i] * 5 + [c_p] * 5,
     "sam6d_fine_assign": [c_p, c_i, c_i, c_i] + [c_p] * 10,
     "sam6d_weighted_procrustes": [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
+    "sam6d_ism_cosine": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_ism_semantic": [c_p, c_i, c_i, c_i, c_i, c_f] + [c_p] * 6,
+    "sam6d_ism_patch_scores": [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    "sam6d_ism_project": [c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
+    "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
 }
 

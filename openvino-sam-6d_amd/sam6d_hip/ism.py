@@ -1,0 +1,94 @@
+"""Host side of the ISM template-scoring path on one MI355X: the functions behind
+Instance_Segmentation_Model.compute_semantic_score / compute_appearance_score / project_template_to_image /
+compute_geometric_score and model.loss.*  (ISM = SAM-6D/Instance_Segmentation_Model in the reference)."""
+import torch
+
+from . import _lib
+from .pem import _empty, _p, _s, gemm
+
+_MODES = {"avg_5": 0, "mean": 1, "max": 2}
+
+
+def pairwise_similarity(query, reference):
+    """ISM/model/loss.py:27-44: query (Nq,D), reference (No,Nt,D) -> (Nq,No,Nt) in [0,1]."""
+    Nq, D = query.shape
+    No, Nt, _ = reference.shape
+    out = _empty((Nq, No, Nt), query)
+    _lib.call("sam6d_ism_cosine", _p(query), _p(reference), Nq, No, Nt, D, _p(out), _s())
+    return out
+
+
+def semantic_select(scores, aggregation="avg_5", confidence_thresh=0.2):
+    """ISM/model/detector.py:265-296 on precomputed scores (Nq,No,Nt).
+    Returns idx_selected (K,) i64, pred_idx_objects (K,) i64, semantic_score (K,), best_template (K,) i64.
+    (one host read-back of K, like the reference's boolean-mask indexing which also synchronises)"""
+    if aggregation not in _MODES:
+        raise NotImplementedError("aggregation_function %r (implemented: avg_5, mean, max)" % aggregation)
+    Nq, No, Nt = scores.shape
+    sem = _empty((Nq,), scores)
+    obj = _empty((Nq,), scores, torch.int32)
+    best = _empty((Nq,), scores, torch.int32)
+    sel = _empty((max(Nq, 1),), scores, torch.int32)
+    nsel = _empty((1,), scores, torch.int32)
+    _lib.call("sam6d_ism_semantic", _p(scores), Nq, No, Nt, _MODES[aggregation], float(confidence_thresh), _p(sem), _p(obj),
+              _p(best), _p(sel), _p(nsel), _s())
+    k = int(nsel.item())
+    sel = sel[:k].long()
+    return sel, obj.long()[sel], sem[sel], best.long()[sel]
+
+
+def patch_similarity(q_appe, ref_sel):
+    """sim (Ns,P,P) = q_appe (Ns,P,D) @ ref_sel (Ns,P,D)^T on the matrix cores (ISM/model/loss.py:54,66)."""
+    Ns, P, D = q_appe.shape
+    sim = _empty((Ns, P, P), q_appe)
+    gemm(q_appe, ref_sel, None, sim, P, P, D, D, D, P, batch=Ns, sA=P * D, sW=P * D, sC=P * P)
+    return sim
+
+
+def patch_scores(sim, q_appe, thred=0.5):
+    """appearance score (loss.py:52-62) and visible ratio (loss.py:64-76) from one similarity tensor."""
+    Ns, P, D = q_appe.shape
+    appe = _empty((Ns,), q_appe)
+    vis = _empty((Ns,), q_appe)
+    _lib.call("sam6d_ism_patch_scores", _p(sim), _p(q_appe), Ns, P, D, float(thred), _p(appe), _p(vis), _s())
+    return appe, vis
+
+
+def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale):
+    """ISM/model/detector.py:209-246: -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3)."""
+    Ns, H, W = masks.shape
+    Npc = pointcloud.shape[1]
+    dev = masks.device
+    masks = masks.to(torch.float32).contiguous()
+    depth = depth.to(torch.int32).contiguous()
+    Kd = K.to(device=dev, dtype=torch.float64).contiguous()
+    best = best_pose.to(torch.int32).contiguous()
+    obj = pred_obj.to(torch.int32).contiguous()
+    part = torch.empty(Ns * 64 * 4, dtype=torch.float64, device=dev)
+    vu = torch.empty(Ns, Npc, 2, dtype=torch.int32, device=dev)
+    xyxy = torch.empty(Ns, 4, dtype=torch.int32, device=dev)
+    tr = torch.empty(Ns, 3, dtype=torch.float32, device=dev)
+    _lib.call("sam6d_ism_project", _p(masks), _p(depth), Kd.data_ptr(), float(depth_scale), _p(poses.contiguous()),
+              _p(pointcloud.contiguous()), _p(best), _p(obj), Ns, H, W, Npc, part.data_ptr(), vu.data_ptr(), xyxy.data_ptr(),
+              _p(tr), _s())
+    return vu, xyxy, tr
+
+
+def compute_iou(xyxy, boxes):
+    """ISM/utils/bbox_utils.py:197-222 incl. the quirk: any non-positive overlap => the python float 0.0."""
+    Ns = xyxy.shape[0]
+    iou = torch.empty(Ns, dtype=torch.float32, device=xyxy.device)
+    flag = torch.empty(1, dtype=torch.int32, device=xyxy.device)
+    a = xyxy.to(torch.int32).contiguous()
+    b = boxes.to(torch.int64).contiguous()
+    _lib.call("sam6d_ism_iou", a.data_ptr(), b.data_ptr(), Ns, _p(iou), flag.data_ptr(), _s())
+    return iou if int(flag.item()) == 1 else 0.0
+
+
+def final_score(sem, appe, geo, vis):
+    """ISM/model/detector.py:384."""
+    Ns = appe.shape[0]
+    out = _empty((Ns,), appe)
+    g = geo if torch.is_tensor(geo) else None
+    _lib.call("sam6d_ism_final_score", _p(sem.contiguous()), _p(appe), _p(g), _p(vis), None, Ns, _p(out), _s())
+    return out

@@ -110,6 +110,54 @@ class PemWeights:
         return dict(self=self_l, cross=cross_l)
 
 
+def _getter(sd, device):
+    return lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_geo(sd, device, p="geo_embedding"):
+    g = _getter(sd, device)
+    w = PemWeights.__new__(PemWeights)
+    w.dev = device
+    w.div_term = g(p + ".embedding.div_term")
+    w.geo_d = Linear(g(p + ".proj_d.weight"), g(p + ".proj_d.bias"))
+    w.geo_a = Linear(g(p + ".proj_a.weight"), g(p + ".proj_a.bias"))
+    return w
+
+
+def pack_geo_transformer(sd, device, p):
+    return PemWeights._geo_transformer(PemWeights.__new__(PemWeights), _getter(sd, device), p)
+
+
+def pack_sparse_to_dense(sd, device, p):
+    g = _getter(sd, device)
+    blk = pack_geo_transformer(sd, device, p + ".sparse_layer")
+    d = p + ".dense_layer"
+    a = d + ".attention.attention"
+    blk["dense"] = dict(scale=g(a + ".scale").reshape(-1), q=Linear(g(a + ".proj_q.weight"), g(a + ".proj_q.bias")),
+                        kv=Linear(torch.cat([g(a + ".proj_k.weight"), g(a + ".proj_v.weight")], 0),
+                                  torch.cat([g(a + ".proj_k.bias"), g(a + ".proj_v.bias")], 0)), **PemWeights._post(g, d))
+    return blk
+
+
+def pack_pe(sd, device, pe):
+    g = _getter(sd, device)
+    w = PemWeights.__new__(PemWeights)
+    w.dev = device
+    w.pe = dict(mlp=[], mlp3=Linear(g(pe + ".mlp3.conv.weight").reshape(C, C), g(pe + ".mlp3.conv.bias")))
+    for k in (1, 2):
+        layers = []
+        for l in range(3):
+            q = "%s.mlp%d.layer%d" % (pe, k, l)
+            wt = g(q + ".conv.weight")
+            wt = wt.reshape(wt.shape[0], wt.shape[1]).contiguous()
+            bn = q + ".normlayer.bn"
+            scale = g(bn + ".weight") / torch.sqrt(g(bn + ".running_var") + 1e-5)
+            shift = g(bn + ".bias") - g(bn + ".running_mean") * scale
+            layers.append(dict(w=wt, scale=scale.contiguous(), shift=shift.contiguous()))
+        w.pe["mlp"].append(layers)
+    return w
+
+
 # ------------------------------------------------------------------------------------------------- primitives
 def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, residual=None, r_off=0, ldr=0,
          colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0):

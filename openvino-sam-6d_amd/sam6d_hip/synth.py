@@ -144,3 +144,22 @@ def kat_inputs(B=2, seed=3, n_dense=2048, n_model=1024, noise=0.0):
     rand = torch.rand(B, 18000, generator=g)
     return dict(dense_pm=pm.contiguous(), dense_fm=fm.contiguous(), dense_po=po, dense_fo=fo,
                 radius=torch.ones(B), model=model, rand=rand, R_gt=Rg, t_gt=tg)
+
+
+class AttrDict(dict):
+    """attribute-style config object like the one PEM/run_inference_custom_pytorch.py:117-125 builds from the yaml"""
+    __getattr__ = dict.__getitem__
+
+
+def default_model_cfg():
+    """The `model:` section of PEM/config/base.yaml:16-54 (values restated here; the yaml itself is not shipped)."""
+    A = AttrDict
+    return A(coarse_npoint=196, fine_npoint=2048,
+             feature_extraction=A(vit_type="vit_base", up_type="linear", embed_dim=768, out_dim=256,
+                                  use_pyramid_feat=True, pretrained=False),
+             geo_embedding=A(sigma_d=0.2, sigma_a=15, angle_k=3, reduction_a="max", hidden_dim=256),
+             coarse_point_matching=A(nblock=3, input_dim=256, hidden_dim=256, out_dim=256, temp=0.1, sim_type="cosine",
+                                     normalize_feat=True, loss_dis_thres=0.15, nproposal1=6000, nproposal2=300),
+             fine_point_matching=A(nblock=3, input_dim=256, hidden_dim=256, out_dim=256, pe_radius1=0.1, pe_radius2=0.2,
+                                   focusing_factor=3, temp=0.1, sim_type="cosine", normalize_feat=True,
+                                   loss_dis_thres=0.15))
