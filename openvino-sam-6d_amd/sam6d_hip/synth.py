@@ -148,7 +148,12 @@ def kat_inputs(B=2, seed=3, n_dense=2048, n_model=1024, noise=0.0):
 
 class AttrDict(dict):
     """attribute-style config object like the one PEM/run_inference_custom_pytorch.py:117-125 builds from the yaml"""
-    __getattr__ = dict.__getitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 def default_model_cfg():
