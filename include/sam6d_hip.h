@@ -99,10 +99,13 @@ int sam6d_linattn_kv(const float* k, const float* v, int B, int J, long ldk, lon
 int sam6d_linattn_focus_q(float* q, const float* scale, const float* ksum, int B, long rows_per_b, long ld,
                           void* stream);
 
-/* PositionalEncoding helpers (PEM/model/fine_point_matching.py:113-144; QueryAndGroup
- * PEM/model/pointnet2/pointnet2_utils.py:326-403): 6-channel grouped rows, and the max over each ball. */
-int sam6d_pe_group_rows(const float* pts, const int* idx, int B, int N, int S, float* rows, void* stream);
-int sam6d_group_max(const float* x, long groups, int S, int C, long ldo, int off, float* out, void* stream);
+/* PositionalEncoding, one scale (PEM/model/fine_point_matching.py:126-139): QueryAndGroup
+ * (PEM/model/pointnet2/pointnet2_utils.py:383-396) + SharedMLP 6->32->64->128 with eval BatchNorm folded to per-channel
+ * scale/shift (PEM/model/pointnet2/pytorch_utils.py:25-50) + max over the ball, fused.  idx (B,N,S) from sam6d_ball_query
+ * with new_xyz = pts + 1e-8; writes out[(b*N+j)*ldo + off + c], c < 128.  S must be a multiple of 32. */
+int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
+                     const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
+                     const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream);
 
 /* y = (x - t) @ R per batch element (PEM/model/fine_point_matching.py:45). */
 int sam6d_rigid_inverse(const float* x, const float* R, const float* t, int B, int N, float* y, void* stream);

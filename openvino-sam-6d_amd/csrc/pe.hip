@@ -1,67 +1,154 @@
-// Helpers of the fine-matching PositionalEncoding (PEM/model/fine_point_matching.py:102-144):
-//   QueryAndGroup (PEM/model/pointnet2/pointnet2_utils.py:326-403) as row-major 6-vectors for the MLP GEMMs, the max
-//   over each ball (torch.amax(dim=3), fine_point_matching.py:131,139), and small row utilities of the dense path.
-// The 1x1-conv SharedMLP layers themselves run on the matrix cores through gemm_nt (BatchNorm folded to a per-column
-// scale/shift in the GEMM epilogue).
+// The fine-matching PositionalEncoding (PEM/model/fine_point_matching.py:102-144) as one fused matrix-core kernel per
+// scale, and small row utilities of the dense path.
 #include "common.h"
 #include "../../include/sam6d_hip.h"
 
-// rows[(b*M + j)*S + s] = { p[idx]-q_j (3), p[idx] (3) },  q_j = pts_j + 1e-8f  (the reference's new_xyz, :117)
-__global__ __launch_bounds__(256) void pe_group_rows_kernel(const float* __restrict__ pts, const int* __restrict__ idx,
-                                                            int N, int S, long total, float* __restrict__ rows) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const long bj = e / S;
-  const long b = bj / N;
-  const int a = idx[e];
-  const float* pb = pts + b * N * 3;
-  const float* pq = pts + bj * 3;
-  const bool ok = a >= 0 && a < N;
-  const float x = ok ? pb[a * 3] : 0.f, y = ok ? pb[a * 3 + 1] : 0.f, z = ok ? pb[a * 3 + 2] : 0.f;
-  const float qx = pq[0] + 0.00000001f, qy = pq[1] + 0.00000001f, qz = pq[2] + 0.00000001f;
-  float* o = rows + e * 6;
-  o[0] = x - qx;
-  o[1] = y - qy;
-  o[2] = z - qz;
-  o[3] = x;
-  o[4] = y;
-  o[5] = z;
-}
+// ===============================================================================================================
+// Fused QueryAndGroup -> SharedMLP(6->32->64->128, Conv2d 1x1 + BatchNorm(eval) + ReLU) -> max over the ball
+// (PEM/model/fine_point_matching.py:126-139; PEM/model/pointnet2/pointnet2_utils.py:383-396; pytorch_utils.py:25-50).
+//
+// One wave owns a query point: its S neighbours are the 32 rows of an MFMA tile (S = 64: two tiles), so the three
+// layers are chained v_mfma_f32_32x32x2_f32 products (3 + 32 + 128 per tile, exact fp32) whose outputs go
+// BN/ReLU -> a private LDS slab -> next layer's A operand; the 128 channel maxima are reduced in registers and only
+// 512 B per point and scale reach HBM (the unfused form wrote and re-read 230 floats per neighbour: 5.6 GB per scale at
+// B = 32).  Weights + BN constants of the scale live in LDS (44 KB), 8 waves per workgroup.
+// Layer-1 features are formed in registers: {p_idx - (p_j + 1e-8), p_idx}  (new_xyz = pts + 1e-8, :117).
+// ===============================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define PM_WAVES 8
+#define PM_PPW 8
+#define PM_WFLOATS (32 * 7 + 64 * 33 + 128 * 65 + 448)
+#define PM_HFLOATS (32 * 33 + 32 * 65)
 
-extern "C" int sam6d_pe_group_rows(const float* pts, const int* idx, int B, int N, int S, float* rows, void* stream) {
-  SAM6D_REQUIRE(pts && idx && rows && B >= 0 && N > 0 && S > 0, "pe_group_rows: bad arguments");
-  const long total = (long)B * N * S;
-  if (total == 0) return 0;
-  hipLaunchKernelGGL(pe_group_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pts,
-                     idx, N, S, total, rows);
-  SAM6D_LAUNCH_CHECK("pe_group_rows");
-}
-
-// out[g, off + c] = max_{s < S} x[(g*S + s), c],  c < C (C % 4 == 0).  One thread per (group, 4 channels).
-__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ x, int S, int C, long groups, long ldo,
-                                                        int off, float* __restrict__ out) {
-  const int c4 = C >> 2;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= groups * c4) return;
-  const long g = e / c4;
-  const int c = (int)(e % c4) * 4;
-  const float* p = x + (g * S) * C + c;
-  float4 m = *reinterpret_cast<const float4*>(p);
-  for (int s = 1; s < S; ++s) {
-    const float4 v = *reinterpret_cast<const float4*>(p + (long)s * C);
-    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+__global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_kernel(
+    const float* __restrict__ pts, const int* __restrict__ idx, int N, int S, long total, const float* __restrict__ W1,
+    const float* __restrict__ sc1, const float* __restrict__ sh1, const float* __restrict__ W2, const float* __restrict__ sc2,
+    const float* __restrict__ sh2, const float* __restrict__ W3, const float* __restrict__ sc3, const float* __restrict__ sh3,
+    float* __restrict__ out, long ldo, int off) {
+  extern __shared__ float lds[];
+  float* w1s = lds;             // [32][7]
+  float* w2s = w1s + 32 * 7;    // [64][33]
+  float* w3s = w2s + 64 * 33;   // [128][65]
+  float* bn = w3s + 128 * 65;   // sc1 32 | sh1 32 | sc2 64 | sh2 64 | sc3 128 | sh3 128
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float* h1 = bn + 448 + wave * PM_HFLOATS;  // [32][33]
+  float* h2 = h1 + 32 * 33;                  // [32][65]
+  for (int e = t; e < 32 * 6; e += PM_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e];
+  for (int e = t; e < 64 * 32; e += PM_WAVES * 64) w2s[(e >> 5) * 33 + (e & 31)] = W2[e];
+  for (int e = t; e < 128 * 64; e += PM_WAVES * 64) w3s[(e >> 6) * 65 + (e & 63)] = W3[e];
+  if (t < 32) { bn[t] = sc1[t]; bn[32 + t] = sh1[t]; }
+  if (t < 64) { bn[64 + t] = sc2[t]; bn[128 + t] = sh2[t]; }
+  if (t < 128) { bn[192 + t] = sc3[t]; bn[320 + t] = sh3[t]; }
+  __syncthreads();
+  const int fr = lane & 31, fk = lane >> 5;
+  const int ntile = S >> 5;
+  for (int i = 0; i < PM_PPW; ++i) {
+    const long p = ((long)blockIdx.x * PM_WAVES + wave) * PM_PPW + i;  // flat point id over B*N
+    if (p >= total) break;
+    const long b = p / N;
+    const float* pb = pts + b * N * 3;
+    const float qx = pts[p * 3] + 0.00000001f, qy = pts[p * 3 + 1] + 0.00000001f, qz = pts[p * 3 + 2] + 0.00000001f;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0, so 0 is a neutral start for the max
+    for (int tile = 0; tile < ntile; ++tile) {
+      const int nb = idx[p * S + tile * 32 + fr];
+      const bool ok = nb >= 0 && nb < N;
+      const float x = ok ? pb[nb * 3] : 0.f, y = ok ? pb[nb * 3 + 1] : 0.f, z = ok ? pb[nb * 3 + 2] : 0.f;
+      // ---- layer 1: K = 6 (k = 2s + fk): {x-qx, y-qy, z-qz, x, y, z}
+      const float f0 = fk ? (y - qy) : (x - qx);
+      const float f1 = fk ? x : (z - qz);
+      const float f2 = fk ? z : y;
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, w1s[fr * 7 + 0 + fk], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, w1s[fr * 7 + 2 + fk], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2, w1s[fr * 7 + 4 + fk], a1, 0, 0, 0);
+      {
+        const float s = bn[fr], h = bn[32 + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = fmaf(a1[r], s, h);
+          h1[((r & 3) + 8 * (r >> 2) + 4 * fk) * 33 + fr] = v > 0.f ? v : 0.f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- layer 2: K = 32, 2 column tiles
+      f32x16 a2[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[c][r] = 0.f;
+#pragma unroll 4
+      for (int s = 0; s < 16; ++s) {
+        const float a = h1[fr * 33 + 2 * s + fk];
+        a2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w2s[fr * 33 + 2 * s + fk], a2[0], 0, 0, 0);
+        a2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w2s[(32 + fr) * 33 + 2 * s + fk], a2[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float s = bn[64 + c * 32 + fr], h = bn[128 + c * 32 + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = fmaf(a2[c][r], s, h);
+          h2[((r & 3) + 8 * (r >> 2) + 4 * fk) * 65 + c * 32 + fr] = v > 0.f ? v : 0.f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- layer 3: K = 64, 4 column tiles
+      f32x16 a3[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a3[c][r] = 0.f;
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const float a = h2[fr * 65 + 2 * s + fk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          a3[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w3s[(c * 32 + fr) * 65 + 2 * s + fk], a3[c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float s = bn[192 + c * 32 + fr], h = bn[320 + c * 32 + fr];
+        float m = mx[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaf(a3[c][r], s, h));
+        mx[c] = m;
+      }
+      __builtin_amdgcn_wave_barrier();  // h1/h2 are rewritten by the next tile only after every lane has read them
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float m = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
+      if (fk == 0) out[p * ldo + off + c * 32 + fr] = m;
+    }
   }
-  *reinterpret_cast<float4*>(out + g * ldo + off + c) = m;
 }
 
-extern "C" int sam6d_group_max(const float* x, long groups, int S, int C, long ldo, int off, float* out, void* stream) {
-  SAM6D_REQUIRE(x && out && groups >= 0 && S > 0 && C > 0 && (C & 3) == 0 && (ldo & 3) == 0 && (off & 3) == 0,
-                "group_max: bad arguments");
-  if (groups == 0) return 0;
-  const long n = groups * (C >> 2);
-  hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, S, C, groups,
-                     ldo, off, out);
-  SAM6D_LAUNCH_CHECK("group_max");
+extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
+                                const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
+                                const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream) {
+  SAM6D_REQUIRE(pts && idx && W1 && sc1 && sh1 && W2 && sc2 && sh2 && W3 && sc3 && sh3 && out, "pe_mlp_max: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && S > 0 && (S & 31) == 0, "pe_mlp_max: nsample must be a multiple of 32 (got %d)", S);
+  const long total = (long)B * N;
+  if (total == 0) return 0;
+  const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  const long per_block = PM_WAVES * PM_PPW;
+  hipLaunchKernelGGL(pe_mlp_max_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(PM_WAVES * 64), lds,
+                     (hipStream_t)stream, pts, idx, N, S, total, W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+  SAM6D_LAUNCH_CHECK("pe_mlp_max");
 }
 
 // y[b, i, :] = (x[b, i, :] - t[b]) @ R[b]   (row vector times R; PEM/model/fine_point_matching.py:45, model_utils.py:262,332)

@@ -31,8 +31,7 @@ SIGNATURES = {
     "sam6d_linattn_focus_k": [c_p, c_p, c_l, c_l, c_p],
     "sam6d_linattn_kv": [c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p, c_p, c_p],
     "sam6d_linattn_focus_q": [c_p, c_p, c_p, c_i, c_l, c_l, c_p],
-    "sam6d_pe_group_rows": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
-    "sam6d_group_max": [c_p, c_l, c_i, c_i, c_l, c_i, c_p, c_p],
+    "sam6d_pe_mlp_max": [c_p, c_p, c_i, c_i, c_i] + [c_p] * 10 + [c_l, c_i, c_p],
     "sam6d_rigid_inverse": [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "sam6d_put_rows": [c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p],
     "sam6d_prepend_bg_point": [c_p, c_i, c_i, c_p, c_p],

@@ -321,16 +321,10 @@ def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32
     for k, (r, ns) in enumerate(((r1, ns1), (r2, ns2))):
         idx = _empty((Bp, N, ns), pts, torch.int32)
         _lib.call("sam6d_ball_query", _p(q), _p(pts), Bp, N, N, float(r), ns, _p(idx), _s())
-        rows = Bp * N * ns
-        x = _empty((rows, 6), pts)
-        _lib.call("sam6d_pe_group_rows", _p(pts), _p(idx), Bp, N, ns, _p(x), _s())
-        kin = 6
-        for l, lay in enumerate(W.pe["mlp"][k]):
-            nout = lay["w"].shape[0]
-            y = _empty((rows, nout), pts)
-            gemm(x, lay["w"], lay["shift"], y, rows, nout, kin, kin, kin, nout, colscale=lay["scale"], act=1)
-            x, kin = y, nout
-        _lib.call("sam6d_group_max", _p(x), Bp * N, ns, 128, 2 * 128, k * 128, _p(feat), _s())
+        L = W.pe["mlp"][k]
+        _lib.call("sam6d_pe_mlp_max", _p(pts), _p(idx), Bp, N, ns, _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
+                  _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),
+                  _p(feat), 2 * 128, k * 128, _s())
     m3 = W.pe["mlp3"]
     gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
          sC=dst_sb, sR=dst_sb)
