@@ -122,9 +122,9 @@ int sam6d_copy_f32(const float* src, float* dst, long n, void* stream);
 int sam6d_l2norm256(const float* x, float* y, long rows, long ldx, long ldy, void* stream);
 
 /* Soft assignment statistics and labels (PEM/utils/model_utils.py:229-235, 320-324): att (B,R,C);
- * rmax/rsum (B,R), cmax/csum (B,C), label1 (B,R-1) i32, label2 (B,C-1) i32. */
+ * rmax/rsum (B,R), cmax/csum (B,C), label1 (B,R-1) i32, label2 (B,C-1) i32; ws: scratch of >= 32*B*C floats. */
 int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
-                      int* label1, int* label2, void* stream);
+                      int* label1, int* label2, float* ws, long ws_floats, void* stream);
 /* Sampling weights (S[1:,1:] * w1 * w2) ** 1.5 -> (B,(R-1)*(C-1)), w1 (B,R-1) (PEM/utils/model_utils.py:234-238). */
 int sam6d_coarse_weights(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
                          const float* csum, const int* label1, const int* label2, float* weights, float* w1,

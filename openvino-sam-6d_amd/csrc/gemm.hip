@@ -4,105 +4,117 @@
 // 186-188, 390-393, 548-550; PEM/model/coarse_point_matching.py:35-38; PEM/model/fine_point_matching.py:47-51) and the
 // feature-similarity contraction (PEM/utils/model_utils.py:144).
 //
-// v_mfma_f32_32x32x2_f32: exact f32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD.  Block tile 128x128x16, 4 waves in a
-// 2x2 grid, each wave a 64x64 sub-tile = 2x2 MFMA tiles (64 accumulator registers).  Operands are staged in LDS with
-// an odd row stride (17 dwords) so the ds_read_b32 fragment reads (32 different rows per lane group) are
-// conflict-free; the MFMA issue time (64 cycles each) dominates, several blocks per CU hide the staging.
+// v_mfma_f32_32x32x2_f32: exact f32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD.  Block tile 128x128x16 (or 64x64x16),
+// 4 waves in a 2x2 grid.  Operands are staged in LDS with an odd row stride (17 dwords) so the ds_read_b32 fragment
+// reads (32 different rows per lane group) are conflict-free; the MFMA issue time (64 cycles each) dominates, several
+// blocks per CU plus the register prefetch of the next K tile hide the staging.
 #include "common.h"
 #include "../../include/sam6d_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GM_BM 128
-#define GM_BN 128
 #define GM_BK 16
 #define GM_LD 17
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                         const float* __restrict__ bias,
-                                                         const float* __restrict__ colscale,
-                                                         const float* __restrict__ residual, float* __restrict__ C,
-                                                         int M, int N, int K, long lda, long ldw, long ldc, long ldr,
-                                                         long sA, long sW, long sC, long sR, float divisor, int act) {
-  __shared__ float As[GM_BM * GM_LD];
-  __shared__ float Bs[GM_BN * GM_LD];
+// BM x BN block tile, 4 waves in a 2x2 grid, each wave (BM/2)x(BN/2) = TM x TN MFMA tiles.  128x128 for the big
+// problems; 64x64 when the 128-tile grid would not fill the 256 CUs (the 197-token sparse layers: M = 6 304 / 12 608).
+// The next K tile is fetched into registers while the current one is multiplied (global latency hidden behind 16-32
+// MFMAs per wave).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ colscale,
+                                                      const float* __restrict__ residual, float* __restrict__ C, int M, int N,
+                                                      int K, long lda, long ldw, long ldc, long ldr, long sA, long sW, long sC,
+                                                      long sR, float divisor, int act) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // MFMA tiles per wave
+  constexpr int RA = BM / 64, RB = BN / 64;  // float4 staging loads per thread
+  __shared__ float As[BM * GM_LD];
+  __shared__ float Bs[BN * GM_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bz = blockIdx.z;
   A += (size_t)bz * sA;
   W += (size_t)bz * sW;
   C += (size_t)bz * sC;
   if (residual) residual += (size_t)bz * sR;
-  const int m0 = blockIdx.x * GM_BM, n0 = blockIdx.y * GM_BN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging map: 128 rows x 16 k = 512 float4; thread t handles rows (t>>2) and (t>>2)+64, k4 = (t&3)*4
+  // staging map: rows (t>>2) + 64*u, k4 = (t&3)*4
   const int sr = t >> 2, sk = (t & 3) * 4;
-  const int ar0 = min(m0 + sr, M - 1), ar1 = min(m0 + sr + 64, M - 1);
-  const int br0 = min(n0 + sr, N - 1), br1 = min(n0 + sr + 64, N - 1);
-  const float* a0p = A + (size_t)ar0 * lda + sk;
-  const float* a1p = A + (size_t)ar1 * lda + sk;
-  const float* b0p = W + (size_t)br0 * ldw + sk;
-  const float* b1p = W + (size_t)br1 * ldw + sk;
+  const float* ap[RA];
+  const float* bp[RB];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) ap[u] = A + (size_t)min(m0 + sr + 64 * u, M - 1) * lda + sk;
+#pragma unroll
+  for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 64 * u, N - 1) * ldw + sk;
   const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
 
-  const int fr = lane & 31, fk = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += GM_BK) {
-    float4 va0, va1, vb0, vb1;
+  float4 va[RA], vb[RB];
+  auto fetch = [&](int k0) {
     if (vec && k0 + GM_BK <= K) {
-      va0 = *reinterpret_cast<const float4*>(a0p + k0);
-      va1 = *reinterpret_cast<const float4*>(a1p + k0);
-      vb0 = *reinterpret_cast<const float4*>(b0p + k0);
-      vb1 = *reinterpret_cast<const float4*>(b1p + k0);
-    } else {
-      float ta[4], tb[4], tc[4], td[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = (k0 + sk + u) < K;
-        ta[u] = ok ? a0p[k0 + u] : 0.f;
-        tb[u] = ok ? a1p[k0 + u] : 0.f;
-        tc[u] = ok ? b0p[k0 + u] : 0.f;
-        td[u] = ok ? b1p[k0 + u] : 0.f;
+      for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+    } else {
+      float tmp[4];
+#pragma unroll
+      for (int u = 0; u < RA; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? ap[u][k0 + e] : 0.f;
+        va[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
       }
-      va0 = make_float4(ta[0], ta[1], ta[2], ta[3]);
-      va1 = make_float4(tb[0], tb[1], tb[2], tb[3]);
-      vb0 = make_float4(tc[0], tc[1], tc[2], tc[3]);
-      vb1 = make_float4(td[0], td[1], td[2], td[3]);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
+        vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+      }
     }
+  };
+
+  const int fr = lane & 31, fk = lane >> 5;
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += GM_BK) {
     __syncthreads();  // previous tile fully consumed
-    float* pa0 = As + sr * GM_LD + sk;
-    float* pa1 = As + (sr + 64) * GM_LD + sk;
-    float* pb0 = Bs + sr * GM_LD + sk;
-    float* pb1 = Bs + (sr + 64) * GM_LD + sk;
-    pa0[0] = va0.x; pa0[1] = va0.y; pa0[2] = va0.z; pa0[3] = va0.w;
-    pa1[0] = va1.x; pa1[1] = va1.y; pa1[2] = va1.z; pa1[3] = va1.w;
-    pb0[0] = vb0.x; pb0[1] = vb0.y; pb0[2] = vb0.z; pb0[3] = vb0.w;
-    pb1[0] = vb1.x; pb1[1] = vb1.y; pb1[2] = vb1.z; pb1[3] = vb1.w;
+#pragma unroll
+    for (int u = 0; u < RA; ++u) {
+      float* d = As + (sr + 64 * u) * GM_LD + sk;
+      d[0] = va[u].x; d[1] = va[u].y; d[2] = va[u].z; d[3] = va[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      float* d = Bs + (sr + 64 * u) * GM_LD + sk;
+      d[0] = vb[u].x; d[1] = vb[u].y; d[2] = vb[u].z; d[3] = vb[u].w;
+    }
     __syncthreads();
+    if (k0 + GM_BK < K) fetch(k0 + GM_BK);  // in flight during the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < GM_BK; kk += 2) {
-      const float a0 = As[(wm + fr) * GM_LD + kk + fk];
-      const float a1 = As[(wm + 32 + fr) * GM_LD + kk + fk];
-      const float b0 = Bs[(wn + fr) * GM_LD + kk + fk];
-      const float b1 = Bs[(wn + 32 + fr) * GM_LD + kk + fk];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(wm + 32 * i + fr) * GM_LD + kk + fk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(wn + 32 * j + fr) * GM_LD + kk + fk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn + j * 32 + fr;
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
@@ -131,10 +143,18 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
   SAM6D_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (ReLU)");
   SAM6D_REQUIRE(batch <= 65535, "gemm_nt: batch must be <= 65535");
   if (M == 0 || N == 0 || batch == 0) return 0;
-  dim3 grid(cdiv(M, GM_BM), cdiv(N, GM_BN), batch);  // M tiles on x (2^31 limit): the PE MLP has 8.4 M rows
-  SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
-  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C, M, N, K,
-                     lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
+  const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
+  if (blocks128 >= 1024) {  // >= 4 workgroups per CU: big tiles
+    dim3 grid(cdiv(M, 128), cdiv(N, 128), batch);  // M tiles on x (2^31 limit)
+    SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C,
+                       M, N, K, lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
+  } else {
+    dim3 grid(cdiv(M, 64), cdiv(N, 64), batch);
+    SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C, M,
+                       N, K, lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
+  }
   SAM6D_LAUNCH_CHECK("gemm_nt");
 }
 

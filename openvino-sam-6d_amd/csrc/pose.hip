@@ -31,16 +31,38 @@ __global__ __launch_bounds__(256) void sa_row_stats_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void sa_col_stats_kernel(const float* __restrict__ att, int R, int C,
-                                                           float* __restrict__ cmax, float* __restrict__ csum) {
+// Column statistics: the R rows are cut into SA_RS slices so that (C/256) x B x SA_RS workgroups stream the matrix
+// (a single thread per column walking all 2049 rows left 7/8 of the chip idle); a second tiny kernel merges the
+// per-slice (max, sum-exp) pairs:  m = max_s m_s,  sum = sum_s sum_s * exp(m_s - m).
+#define SA_RS 16
+__global__ __launch_bounds__(256) void sa_col_stats_part_kernel(const float* __restrict__ att, int R, int C,
+                                                                float* __restrict__ pmax, float* __restrict__ psum) {
+  const int b = blockIdx.y, rs = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int per = (R + SA_RS - 1) / SA_RS;
+  const int r0 = rs * per, r1 = min(R, r0 + per);
+  const float* a = att + (size_t)b * R * C + c;
+  float mx = -INFINITY;
+  for (int r = r0; r < r1; ++r) mx = fmaxf(mx, a[(size_t)r * C]);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += expf(a[(size_t)r * C] - mx);
+  pmax[((size_t)b * SA_RS + rs) * C + c] = mx;
+  psum[((size_t)b * SA_RS + rs) * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void sa_col_stats_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                                 int C, float* __restrict__ cmax, float* __restrict__ csum) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const float* a = att + (size_t)b * R * C + c;
   float mx = -INFINITY;
-  for (int r = 0; r < R; ++r) mx = fmaxf(mx, a[(size_t)r * C]);
+  for (int rs = 0; rs < SA_RS; ++rs) mx = fmaxf(mx, pmax[((size_t)b * SA_RS + rs) * C + c]);
   float s = 0.f;
-  for (int r = 0; r < R; ++r) s += expf(a[(size_t)r * C] - mx);
+  for (int rs = 0; rs < SA_RS; ++rs) {
+    const float m = pmax[((size_t)b * SA_RS + rs) * C + c];
+    if (m != -INFINITY) s += psum[((size_t)b * SA_RS + rs) * C + c] * expf(m - mx);  // empty slices hold (-inf, 0)
+  }
   cmax[(size_t)b * C + c] = mx;
   csum[(size_t)b * C + c] = s;
 }
@@ -84,44 +106,71 @@ __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restr
   if (lane == 0) label1[w] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
-// label2[b, c-1] = argmax_r S[b, r, c] (first maximum), c = 1..C-1  -- one thread per column
-__global__ __launch_bounds__(256) void sa_col_labels_kernel(const float* __restrict__ att, int R, int C,
-                                                            const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                            const float* __restrict__ cmax, const float* __restrict__ csum,
-                                                            int* __restrict__ label2) {
-  const int b = blockIdx.y;
+// label2[b, c-1] = argmax_r S[b, r, c] (first maximum), c = 1..C-1: row-sliced like the column statistics; the merge
+// keeps the lowest row on ties, so the result equals the sequential scan's.
+__global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __restrict__ att, int R, int C,
+                                                                 const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                                 const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                                 float* __restrict__ pbest, int* __restrict__ pidx) {
+  const int b = blockIdx.y, rs = blockIdx.z;
   const int c = blockIdx.x * 256 + threadIdx.x + 1;
   if (c >= C) return;
+  const int per = (R + SA_RS - 1) / SA_RS;
+  const int r0 = rs * per, r1 = min(R, r0 + per);
   const float* a = att + (size_t)b * R * C + c;
   const float cm = cmax[(size_t)b * C + c], cs = csum[(size_t)b * C + c];
   const float* rm = rmax + (size_t)b * R;
-  const float* rs = rsum + (size_t)b * R;
+  const float* rsm = rsum + (size_t)b * R;
   float best = -INFINITY;
-  int bi = 0;
-  for (int r = 0; r < R; ++r) {
-    const float v = sa_value(a[(size_t)r * C], rm[r], rs[r], cm, cs);
+  int bi = 0x7fffffff;
+  for (int r = r0; r < r1; ++r) {
+    const float v = sa_value(a[(size_t)r * C], rm[r], rsm[r], cm, cs);
     if (v > best) {
       best = v;
       bi = r;
     }
   }
-  label2[(size_t)b * (C - 1) + (c - 1)] = bi;
+  pbest[((size_t)b * SA_RS + rs) * C + c] = best;
+  pidx[((size_t)b * SA_RS + rs) * C + c] = bi;
+}
+
+__global__ __launch_bounds__(256) void sa_col_labels_merge_kernel(const float* __restrict__ pbest, const int* __restrict__ pidx,
+                                                                  int C, int* __restrict__ label2) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x + 1;
+  if (c >= C) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int rs = 0; rs < SA_RS; ++rs) {  // slices are in increasing row order: strict > keeps the first maximum
+    const float v = pbest[((size_t)b * SA_RS + rs) * C + c];
+    if (v > best) {
+      best = v;
+      bi = pidx[((size_t)b * SA_RS + rs) * C + c];
+    }
+  }
+  label2[(size_t)b * (C - 1) + (c - 1)] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
 extern "C" int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
-                                 int* label1, int* label2, void* stream) {
-  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2, "soft_assign: null pointer");
+                                 int* label1, int* label2, float* ws, long ws_floats, void* stream) {
+  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && ws, "soft_assign: null pointer");
   SAM6D_REQUIRE(B >= 0 && R >= 2 && C >= 2 && B <= 65535, "soft_assign: bad sizes");
+  SAM6D_REQUIRE(ws_floats >= 2L * B * SA_RS * C, "soft_assign: workspace needs 2*B*%d*C floats", SA_RS);
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  float* p0 = ws;
+  float* p1 = ws + (size_t)B * SA_RS * C;
   const long rows = (long)B * R;
   hipLaunchKernelGGL(sa_row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, att, C, rows, rmax, rsum);
-  hipLaunchKernelGGL(sa_col_stats_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, att, R, C, cmax, csum);
+  hipLaunchKernelGGL(sa_col_stats_part_kernel, dim3(cdiv(C, 256), B, SA_RS), dim3(256), 0, s, att, R, C, p0, p1);
+  hipLaunchKernelGGL(sa_col_stats_merge_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, p0, p1, C, cmax, csum);
   const long lrows = (long)B * (R - 1);
   hipLaunchKernelGGL(sa_row_labels_kernel, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
                      cmax, csum, label1);
-  hipLaunchKernelGGL(sa_col_labels_kernel, dim3(cdiv(C - 1, 256), B), dim3(256), 0, s, att, R, C, rmax, rsum, cmax, csum,
-                     label2);
+  hipLaunchKernelGGL(sa_col_labels_part_kernel, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, rmax, rsum, cmax,
+                     csum, p0, reinterpret_cast<int*>(p1));
+  hipLaunchKernelGGL(sa_col_labels_merge_kernel, dim3(cdiv(C - 1, 256), B), dim3(256), 0, s, p0, reinterpret_cast<const int*>(p1),
+                     C, label2);
   SAM6D_LAUNCH_CHECK("soft_assign");
 }
 

@@ -344,8 +344,9 @@ def soft_assign(att):
     B, R, Cn = att.shape
     st = dict(rmax=_empty((B, R), att), rsum=_empty((B, R), att), cmax=_empty((B, Cn), att), csum=_empty((B, Cn), att),
               l1=_empty((B, R - 1), att, torch.int32), l2=_empty((B, Cn - 1), att, torch.int32))
+    ws = _empty((32 * B * Cn,), att)
     _lib.call("sam6d_soft_assign", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
-              _p(st["l1"]), _p(st["l2"]), _s())
+              _p(st["l1"]), _p(st["l2"]), _p(ws), ws.numel(), _s())
     return st
 
 
