@@ -69,6 +69,12 @@ int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float
                   float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
                   long sC, long sR, float divisor, int act, void* stream);
 
+/* Matrix-core arithmetic of gemm_nt / geo_embed: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
+ * 1 = fp16 x3 split (x = hi + lo in fp16, 3 MFMAs, ~1e-6 relative; default).  Both replace the same F.linear call
+ * sites (PEM/model/transformer.py:127-129); the mode is process-wide. */
+int sam6d_set_matmul_mode(int mode);
+int sam6d_get_matmul_mode(void);
+
 /* nn.LayerNorm(256) over `rows` rows (PEM/model/transformer.py:158,189,436,597).  eps as in torch (1e-5). */
 int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, float* y, long rows, long ldx, long ldy,
                        float eps, void* stream);

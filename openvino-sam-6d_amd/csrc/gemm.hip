@@ -134,6 +134,165 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision variant ("fp16 x3"): every fp32 operand x is cut into x_hi = fp16(x), x_lo = fp16(x - x_hi)
+// (22 significand bits together) and a.b is evaluated as a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on
+// v_mfma_f32_32x32x16_f16: fp16 products are exact in the fp32 accumulator, the dropped a_lo.b_lo term is 2^-22
+// relative.  Three MFMAs at 16x the fp32-MFMA rate = 5.3x the exact kernel's ceiling at ~1e-6 relative error
+// (tests compare both modes with the same golden vectors).  The split happens while staging the tile into LDS.
+// LDS rows are 40 halves (80 B): 16 consecutive rows land on 16 different 16-byte slots of the 256-B bank row, so
+// the ds_read_b128 fragment reads are conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#define H_BK 32
+#define H_LD 40
+
+__device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
+  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+  hi = half4{h0, h1, h2, h3};
+  lo = half4{(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
+             (_Float16)(v.w - (float)h3)};
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* __restrict__ colscale,
+                                                         const float* __restrict__ residual, float* __restrict__ C, int M,
+                                                         int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
+                                                         long sC, long sR, float divisor, int act) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int RA = BM / 32, RB = BN / 32;  // float4 staging loads per thread (32 rows x 8 float4 per pass)
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[BM * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[BN * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bl[BN * H_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bz = blockIdx.z;
+  A += (size_t)bz * sA;
+  W += (size_t)bz * sW;
+  C += (size_t)bz * sC;
+  if (residual) residual += (size_t)bz * sR;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sr = t >> 3, sk = (t & 7) * 4;
+  const float* ap[RA];
+  const float* bp[RB];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) ap[u] = A + (size_t)min(m0 + sr + 32 * u, M - 1) * lda + sk;
+#pragma unroll
+  for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk;
+  const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
+
+  float4 va[RA], vb[RB];
+  auto fetch = [&](int k0) {
+    if (vec && k0 + H_BK <= K) {
+#pragma unroll
+      for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
+#pragma unroll
+      for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+    } else {
+      float tmp[4];
+#pragma unroll
+      for (int u = 0; u < RA; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? ap[u][k0 + e] : 0.f;
+        va[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
+        vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+      }
+    }
+  };
+
+  const int fr = lane & 31, fk = lane >> 5;
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += H_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RA; ++u) {
+      half4 hi, lo;
+      split4(va[u], hi, lo);
+      *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
+      *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      half4 hi, lo;
+      split4(vb[u], hi, lo);
+      *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
+      *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
+    }
+    __syncthreads();
+    if (k0 + H_BK < K) fetch(k0 + H_BK);
+#pragma unroll
+    for (int ks = 0; ks < H_BK; ks += 16) {
+      half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+        al[i] = *reinterpret_cast<const half8*>(&Al[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+        bl[j] = *reinterpret_cast<const half8*>(&Bl[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + j * 32 + fr;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+      const float cs = colscale ? colscale[col] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (row < M) {
+          float v = acc[i][j][r];
+          if (divisor != 1.0f) v = v / divisor;
+          v = colscale ? fmaf(v, cs, bv) : v + bv;
+          if (act == 1) v = v > 0.f ? v : 0.f;
+          if (residual) v += residual[(size_t)row * ldr + col];
+          C[(size_t)row * ldc + col] = v;
+        }
+      }
+    }
+}
+
+// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp16 x3 split (default).  Process-wide; set before launching.
+static int g_matmul_mode = 1;
+extern "C" int sam6d_set_matmul_mode(int mode) {
+  SAM6D_REQUIRE(mode == 0 || mode == 1, "set_matmul_mode: 0 (exact fp32 MFMA) or 1 (fp16 x3 split)");
+  g_matmul_mode = mode;
+  return 0;
+}
+extern "C" int sam6d_get_matmul_mode(void) { return g_matmul_mode; }
+
 extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale,
                              const float* residual, float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr,
                              int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream) {
@@ -144,17 +303,19 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
   SAM6D_REQUIRE(batch <= 65535, "gemm_nt: batch must be <= 65535");
   if (M == 0 || N == 0 || batch == 0) return 0;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
-  if (blocks128 >= 1024) {  // >= 4 workgroups per CU: big tiles
-    dim3 grid(cdiv(M, 128), cdiv(N, 128), batch);  // M tiles on x (2^31 limit)
-    SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C,
-                       M, N, K, lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
+  const bool big = blocks128 >= 1024;  // >= 4 workgroups per CU: big tiles
+  dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64), batch);  // M tiles on x (2^31 limit)
+  SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
+  hipStream_t st = (hipStream_t)stream;
+#define GEMM_LAUNCH(KERNEL)                                                                                              \
+  hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
+                     sC, sR, divisor, act)
+  if (g_matmul_mode == 1 && K >= 32) {
+    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>));
   } else {
-    dim3 grid(cdiv(M, 64), cdiv(N, 64), batch);
-    SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, A, W, bias, colscale, residual, C, M,
-                       N, K, lda, ldw, ldc, ldr, sA, sW, sC, sR, divisor, act);
+    if (big) GEMM_LAUNCH((gemm_nt_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_kernel<64, 64>));
   }
+#undef GEMM_LAUNCH
   SAM6D_LAUNCH_CHECK("gemm_nt");
 }
 

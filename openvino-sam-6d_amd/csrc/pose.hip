@@ -34,8 +34,11 @@ __global__ __launch_bounds__(256) void sa_row_stats_kernel(const float* __restri
 // Column statistics: the R rows are cut into SA_RS slices so that (C/256) x B x SA_RS workgroups stream the matrix
 // (a single thread per column walking all 2049 rows left 7/8 of the chip idle); a second tiny kernel merges the
 // per-slice (max, sum-exp) pairs:  m = max_s m_s,  sum = sum_s sum_s * exp(m_s - m).
-#define SA_RS 16
-__global__ __launch_bounds__(256) void sa_col_stats_part_kernel(const float* __restrict__ att, int R, int C,
+// Small matrices (the 197 x 197 coarse attention) use ONE slice: the column sum is then the plain sequential fp32 sum
+// in row order, which is what the reference's softmax(dim=1) computes -- the sampled hypothesis indices downstream
+// stay bit-exact with the reference when the same attention matrix is injected.
+#define SA_RS_MAX 16
+__global__ __launch_bounds__(256) void sa_col_stats_part_kernel(const float* __restrict__ att, int R, int C, int SA_RS,
                                                                 float* __restrict__ pmax, float* __restrict__ psum) {
   const int b = blockIdx.y, rs = blockIdx.z;
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -52,10 +55,16 @@ __global__ __launch_bounds__(256) void sa_col_stats_part_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void sa_col_stats_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
-                                                                 int C, float* __restrict__ cmax, float* __restrict__ csum) {
+                                                                 int C, int SA_RS, float* __restrict__ cmax,
+                                                                 float* __restrict__ csum) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  if (SA_RS == 1) {  // single slice: pass the sequential sum through untouched
+    cmax[(size_t)b * C + c] = pmax[(size_t)b * C + c];
+    csum[(size_t)b * C + c] = psum[(size_t)b * C + c];
+    return;
+  }
   float mx = -INFINITY;
   for (int rs = 0; rs < SA_RS; ++rs) mx = fmaxf(mx, pmax[((size_t)b * SA_RS + rs) * C + c]);
   float s = 0.f;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restr
 
 // label2[b, c-1] = argmax_r S[b, r, c] (first maximum), c = 1..C-1: row-sliced like the column statistics; the merge
 // keeps the lowest row on ties, so the result equals the sequential scan's.
-__global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __restrict__ att, int R, int C,
+__global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __restrict__ att, int R, int C, int SA_RS,
                                                                  const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                                  const float* __restrict__ cmax, const float* __restrict__ csum,
                                                                  float* __restrict__ pbest, int* __restrict__ pidx) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void sa_col_labels_merge_kernel(const float* __restrict__ pbest, const int* __restrict__ pidx,
-                                                                  int C, int* __restrict__ label2) {
+                                                                  int C, int SA_RS, int* __restrict__ label2) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x + 1;
   if (c >= C) return;
@@ -155,6 +164,7 @@ extern "C" int sam6d_soft_assign(const float* att, int B, int R, int C, float* r
                                  int* label1, int* label2, float* ws, long ws_floats, void* stream) {
   SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && ws, "soft_assign: null pointer");
   SAM6D_REQUIRE(B >= 0 && R >= 2 && C >= 2 && B <= 65535, "soft_assign: bad sizes");
+  const int SA_RS = (R <= 256) ? 1 : SA_RS_MAX;
   SAM6D_REQUIRE(ws_floats >= 2L * B * SA_RS * C, "soft_assign: workspace needs 2*B*%d*C floats", SA_RS);
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -162,15 +172,15 @@ extern "C" int sam6d_soft_assign(const float* att, int B, int R, int C, float* r
   float* p1 = ws + (size_t)B * SA_RS * C;
   const long rows = (long)B * R;
   hipLaunchKernelGGL(sa_row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, att, C, rows, rmax, rsum);
-  hipLaunchKernelGGL(sa_col_stats_part_kernel, dim3(cdiv(C, 256), B, SA_RS), dim3(256), 0, s, att, R, C, p0, p1);
-  hipLaunchKernelGGL(sa_col_stats_merge_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, p0, p1, C, cmax, csum);
+  hipLaunchKernelGGL(sa_col_stats_part_kernel, dim3(cdiv(C, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, p0, p1);
+  hipLaunchKernelGGL(sa_col_stats_merge_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, p0, p1, C, SA_RS, cmax, csum);
   const long lrows = (long)B * (R - 1);
   hipLaunchKernelGGL(sa_row_labels_kernel, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
                      cmax, csum, label1);
-  hipLaunchKernelGGL(sa_col_labels_part_kernel, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, rmax, rsum, cmax,
-                     csum, p0, reinterpret_cast<int*>(p1));
+  hipLaunchKernelGGL(sa_col_labels_part_kernel, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, rmax, rsum,
+                     cmax, csum, p0, reinterpret_cast<int*>(p1));
   hipLaunchKernelGGL(sa_col_labels_merge_kernel, dim3(cdiv(C - 1, 256), B), dim3(256), 0, s, p0, reinterpret_cast<const int*>(p1),
-                     C, label2);
+                     C, SA_RS, label2);
   SAM6D_LAUNCH_CHECK("soft_assign");
 }
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
+    "sam6d_set_matmul_mode": [c_i],
     "sam6d_layernorm256": [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_f, c_p],
     "sam6d_geo_embedding": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_geo_indices": [c_p, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_p],
@@ -70,6 +71,8 @@ def load():
     lib.sam6d_last_error.restype = ctypes.c_char_p
     lib.sam6d_last_error.argtypes = []
     lib.sam6d_abi_version.restype = c_i
+    lib.sam6d_get_matmul_mode.restype = c_i
+    lib.sam6d_get_matmul_mode.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args

@@ -20,7 +20,7 @@ def test_header_symbols_exported_and_bound():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "symbol %s declared in sam6d_hip.h but not exported" % n
-    bound = set(_lib.SIGNATURES) | {"sam6d_last_error", "sam6d_abi_version"}
+    bound = set(_lib.SIGNATURES) | {"sam6d_last_error", "sam6d_abi_version", "sam6d_get_matmul_mode"}
     assert set(names) == bound, (set(names) ^ bound)
     _lib.load()
     assert _lib.load().sam6d_abi_version() >= 1
@@ -32,7 +32,7 @@ def test_every_declaration_cites_the_reference():
     blocks = re.findall(r"/\*((?:(?!\*/).)*?)\*/\s*int\s+(sam6d_[a-z0-9_]+)\s*\(", txt, flags=re.S)
     assert blocks
     for comment, name in blocks:
-        if name in ("sam6d_abi_version",):
+        if name in ("sam6d_abi_version", "sam6d_get_matmul_mode"):
             continue
         assert re.search(r"\.(cpp|py|h):\d+", comment), "%s: no reference file:line in its comment" % name
 

@@ -401,3 +401,29 @@ def test_pem_end_to_end_vs_reference(dev, W, tag):
     _close(R, g[tag + "_R"], 1e-4, "final R")
     _close(t, g[tag + "_t"], 1e-4, "final t")
     _close(s, g[tag + "_score"], 1e-4, "final score")
+
+
+def test_matmul_modes_error_vs_fp64(dev):
+    """exact fp32 MFMA (mode 0) vs fp16x3 split (mode 1, default): both against an fp64 reference; the split mode must
+    stay within a few 1e-6 of the result's scale (it carries 22 of fp32's 24 significand bits per operand)."""
+    from sam6d_hip import _lib, pem
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 4096, 256, 256
+    A = torch.randn(M, K, generator=g) * 2
+    A[:, :8] *= 1e-3  # small-magnitude columns: lo parts fall into fp16 subnormals
+    Wt = torch.randn(N, K, generator=g) / 16
+    want = A.double() @ Wt.double().t()
+    Ad, Wd = A.to(dev), Wt.to(dev)
+    errs = {}
+    prev = _lib.load().sam6d_get_matmul_mode()
+    try:
+        for mode in (0, 1):
+            _lib.call("sam6d_set_matmul_mode", mode)
+            out = torch.empty(M, N, device=dev)
+            pem.gemm(Ad, Wd, None, out, M, N, K, K, K, N)
+            errs[mode] = float((out.cpu().double() - want).abs().max())
+    finally:
+        _lib.call("sam6d_set_matmul_mode", prev)
+    scale = float(want.abs().max())
+    print("\nmatmul max abs err vs fp64: exact-fp32 %.2e, fp16x3 %.2e (result scale %.1f)" % (errs[0], errs[1], scale))
+    assert errs[0] < 2e-6 * scale and errs[1] < 4e-6 * scale
