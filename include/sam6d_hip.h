@@ -91,6 +91,13 @@ int sam6d_geo_indices(const float* points, int B, int n, float sigma_d, float fa
 int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, const float* Wd, const float* bd,
                     const float* Wa, const float* ba, int hidden, float* out, void* stream);
 
+/* fp16 x3 split-precision form of sam6d_geo_embed (same call site, PEM/model/transformer.py:343-363): w_packed =
+ * [8][2][256][64] halves = per 32-wide K chunk, per matrix (proj_d, proj_a), per output column: 32 hi | 32 lo halves of
+ * weight*1024, produced with sam6d_split_f16 (x -> fp16(x*scale), fp16(x*scale - hi)) at weight-load time. */
+int sam6d_split_f16(const float* x, long n, float scale, void* hi, void* lo, void* stream);
+int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
+                       const float* ba, int hidden, float* out, void* stream);
+
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).
  * RPE form: qp (B,n,4,256) = per-head query folded through proj_p, E (B,n,m,256); pass both NULL for the plain form. */

@@ -190,6 +190,160 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- 3b. embedding, fp16 x3
+// Same contraction on v_mfma_f32_32x32x16_f16 with split operands (gemm.hip explains the arithmetic): 64 pairs
+// (256 generated rows) per workgroup of 8 waves; wave (ph, cq) owns pairs [32 ph, +32) x columns [64 cq, +64) for all
+// four row groups, so the max over the 3 angular rows and the final add stay in registers.  proj_d / proj_a arrive
+// pre-split and pre-tiled: Wp[kc][mat][col][64] = 32 hi halves | 32 lo halves of (W * 1024)[col][32 kc .. +32]
+// (sam6d_split_f16 + a host-side re-tiling at weight-load time); 2^-10 is undone in the epilogue (exact).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define GH_P 64
+#define GH_LD 40
+#define GH_LDS_BYTES ((4 * GH_P * GH_LD * 2 + 2 * 256 * GH_LD * 2) * 2 + 4 * GH_P * 4)
+
+__global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
+                                                           const _Float16* __restrict__ Wp, const float* __restrict__ bd,
+                                                           const float* __restrict__ ba, float* __restrict__ out, long total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][40]
+  _Float16* Al = Ah + 4 * GH_P * GH_LD;
+  _Float16* Bh = Al + 4 * GH_P * GH_LD;                 // [2*256][40]
+  _Float16* Bl = Bh + 2 * 256 * GH_LD;
+  float* xs = reinterpret_cast<float*>(Bl + 2 * 256 * GH_LD);  // [4][64]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long p0 = (long)blockIdx.x * GH_P;
+  if (t < GH_P) {
+    const float4 v = idx4[min(p0 + t, total - 1)];
+    xs[0 * GH_P + t] = v.x;
+    xs[1 * GH_P + t] = v.y;
+    xs[2 * GH_P + t] = v.z;
+    xs[3 * GH_P + t] = v.w;
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.f;
+  __syncthreads();
+  const int grow = t & 255, gf0 = (t >> 8) * 8;  // A generation: row, first of the 8 frequencies of this chunk
+  const float xrow = xs[grow];
+  const int fr = lane & 31, fk = lane >> 5;
+  const int ph = wave & 1, wn = (wave >> 1) * 64;
+  for (int kc = 0; kc < 8; ++kc) {
+    // weights of this 32-wide K chunk: 2 mats x 256 cols x (32 hi | 32 lo) halves = 4096 x 16 B, 8 per thread
+    uint4 wv[8];
+    const uint4* src = reinterpret_cast<const uint4*>(Wp) + (size_t)kc * 4096;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = src[t + 512 * u];
+    half8 ahi[2], alo[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float sv, cv;
+      sincosf(xrow * div_term[kc * 16 + gf0 + u], &sv, &cv);
+      const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
+      ahi[u >> 2][(u & 3) * 2] = sh;
+      ahi[u >> 2][(u & 3) * 2 + 1] = ch;
+      alo[u >> 2][(u & 3) * 2] = (_Float16)(sv - (float)sh);
+      alo[u >> 2][(u & 3) * 2 + 1] = (_Float16)(cv - (float)ch);
+    }
+    __syncthreads();  // previous chunk consumed
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int id = t + 512 * u;             // 16-byte unit: [mat*256+col][8 units: 4 hi | 4 lo]
+      const int rowc = id >> 3, part = id & 7;
+      _Float16* dst = ((part < 4) ? Bh : Bl) + rowc * GH_LD + (part & 3) * 8;
+      *reinterpret_cast<uint4*>(dst) = wv[u];
+    }
+    *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi[0];
+    *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0 + 8]) = ahi[1];
+    *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo[0];
+    *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0 + 8]) = alo[1];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 32; ks += 16) {
+      half8 bh[2][2], bl[2][2];  // [mat][col tile]
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[mt][j] = *reinterpret_cast<const half8*>(&Bh[(mt * 256 + wn + 32 * j + fr) * GH_LD + ks + 8 * fk]);
+          bl[mt][j] = *reinterpret_cast<const half8*>(&Bl[(mt * 256 + wn + 32 * j + fr) * GH_LD + ks + 8 * fk]);
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const half8 ah = *reinterpret_cast<const half8*>(&Ah[(g * GH_P + ph * 32 + fr) * GH_LD + ks + 8 * fk]);
+        const half8 al = *reinterpret_cast<const half8*>(&Al[(g * GH_P + ph * 32 + fr) * GH_LD + ks + 8 * fk]);
+        const int mt = g ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt][j], acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt][j], acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt][j], acc[g][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const float unscale = 1.0f / 1024.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn + j * 32 + fr;
+    const float vbd = bd[col], vba = ba[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long e = p0 + ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (e < total) {
+        const float d = acc[0][j][r] * unscale + vbd;
+        const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) * unscale + vba;
+        out[e * 256 + col] = d + a;
+      }
+    }
+  }
+}
+
+// x -> (hi, lo) fp16 pair of x*scale: hi = fp16(x*scale), lo = fp16(x*scale - hi)   (weight packing, load time)
+__global__ void split_f16_kernel(const float* __restrict__ x, long n, float scale, _Float16* __restrict__ hi,
+                                 _Float16* __restrict__ lo) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float v = x[e] * scale;
+  const _Float16 h = (_Float16)v;
+  hi[e] = h;
+  lo[e] = (_Float16)(v - (float)h);
+}
+
+extern "C" int sam6d_split_f16(const float* x, long n, float scale, void* hi, void* lo, void* stream) {
+  SAM6D_REQUIRE(x && hi && lo && n >= 0, "split_f16: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, scale,
+                     reinterpret_cast<_Float16*>(hi), reinterpret_cast<_Float16*>(lo));
+  SAM6D_LAUNCH_CHECK("split_f16");
+}
+
+extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
+                                  const float* ba, int hidden, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && w_packed && bd && ba && out, "geo_embed_h3: null pointer");
+  SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed_h3: hidden_dim must be 256");
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed) & 15) == 0, "geo_embed_h3: idx_ws/weights must be 16-byte aligned");
+  if (pairs == 0) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_embed_h3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES);
+    if (e != hipSuccess) {
+      sam6d_set_error("geo_embed_h3: cannot reserve %d bytes of LDS: %s", GH_LDS_BYTES, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES,
+                     (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), div_term,
+                     reinterpret_cast<const _Float16*>(w_packed), bd, ba, out, pairs);
+  SAM6D_LAUNCH_CHECK("geo_embed_h3");
+}
+
 static int geo_check(int B, int n, int angle_k, int hidden) {
   SAM6D_REQUIRE(angle_k == 3 && hidden == 256, "geo_embedding: only angle_k=3, hidden_dim=256 (PEM/config/base.yaml:26-31)");
   SAM6D_REQUIRE(B >= 0 && n >= 4 && n <= 256, "geo_embedding: need 4 <= n <= 256 (got %d)", n);

@@ -221,9 +221,28 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     factor_a = 180.0 / (sigma_a * math.pi)
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
     with _Timed("geo_embed_kernel"):
-        _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
-                  _p(W.geo_a.b), C, _p(out), _s())
+        if _lib.load().sam6d_get_matmul_mode() == 1:
+            _lib.call("sam6d_geo_embed_h3", _p(idx), B * n * n, _p(W.div_term), geo_packed(W).data_ptr(), _p(W.geo_d.b),
+                      _p(W.geo_a.b), C, _p(out), _s())
+        else:
+            _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
+                      _p(W.geo_a.b), C, _p(out), _s())
     return out
+
+
+def geo_packed(W):
+    """proj_d / proj_a split into fp16 hi/lo (scaled by 1024) and tiled [kc][mat][col][32 hi | 32 lo] for
+    geo_embed_h3_kernel; built once per weight set.  The split is a HIP kernel, the re-tiling pure data movement."""
+    pk = getattr(W, "_geo_pack", None)
+    if pk is None:
+        both = torch.stack([W.geo_d.w, W.geo_a.w], 0).contiguous()  # (2, 256 cols, 256 k)
+        hi = torch.empty(both.shape, dtype=torch.float16, device=both.device)
+        lo = torch.empty_like(hi)
+        _lib.call("sam6d_split_f16", _p(both), both.numel(), 1024.0, hi.data_ptr(), lo.data_ptr(), _s())
+        t = lambda x: x.view(2, C, 8, 32).permute(2, 0, 1, 3)  # (kc, mat, col, 32)
+        pk = torch.cat([t(hi), t(lo)], dim=3).contiguous()     # (8, 2, 256, 64)
+        W._geo_pack = pk
+    return pk
 
 
 def rpe_self_layer(x, E, L):
