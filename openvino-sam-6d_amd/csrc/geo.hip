@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float om = xrow * div_term[(k0 >> 1) + gf0 + u];
-      sincosf(om, &sv[u], &cv[u]);
+      fast_sincosf(om, &sv[u], &cv[u]);
     }
     __syncthreads();  // previous chunk consumed
 #pragma unroll
@@ -232,23 +232,27 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   const float xrow = xs[grow];
   const int fr = lane & 31, fk = lane >> 5;
   const int ph = wave & 1, wn = (wave >> 1) * 64;
-  for (int kc = 0; kc < 8; ++kc) {
-    // weights of this 32-wide K chunk: 2 mats x 256 cols x (32 hi | 32 lo) halves = 4096 x 16 B, 8 per thread
-    uint4 wv[8];
+  // software pipeline: the weights and the sinusoid rows of chunk kc+1 are produced (global loads + ~250 VALU per lane)
+  // after chunk kc's fragments are in LDS, in the same basic block as chunk kc's MFMAs, so the matrix pipe covers them
+  uint4 wv[8];
+  half8 ahi[2], alo[2];
+  auto produce = [&](int kc) {
     const uint4* src = reinterpret_cast<const uint4*>(Wp) + (size_t)kc * 4096;
 #pragma unroll
     for (int u = 0; u < 8; ++u) wv[u] = src[t + 512 * u];
-    half8 ahi[2], alo[2];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       float sv, cv;
-      sincosf(xrow * div_term[kc * 16 + gf0 + u], &sv, &cv);
+      fast_sincosf(xrow * div_term[kc * 16 + gf0 + u], &sv, &cv);
       const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
       ahi[u >> 2][(u & 3) * 2] = sh;
       ahi[u >> 2][(u & 3) * 2 + 1] = ch;
       alo[u >> 2][(u & 3) * 2] = (_Float16)(sv - (float)sh);
       alo[u >> 2][(u & 3) * 2 + 1] = (_Float16)(cv - (float)ch);
     }
+  };
+  produce(0);
+  for (int kc = 0; kc < 8; ++kc) {
     __syncthreads();  // previous chunk consumed
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
     *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo[0];
     *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0 + 8]) = alo[1];
     __syncthreads();
+    if (kc + 1 < 8) produce(kc + 1);
 #pragma unroll
     for (int ks = 0; ks < 32; ks += 16) {
       half8 bh[2][2], bl[2][2];  // [mat][col tile]
