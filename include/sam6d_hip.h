@@ -80,7 +80,8 @@ int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, fl
                        float eps, void* stream);
 
 /* replaces GeometricStructureEmbedding.forward (PEM/model/transformer.py:343-363; indices :306-341; sinusoid :259-285).
- * points (B,n,3) (bg point already prepended) -> out (B,n,n,256).  Workspaces: knn_ws (B*n*3) i32, idx_ws (B*n*n*4) f32. */
+ * points (B,n,3) (bg point already prepended) -> out (B,n,n,256).  Workspaces: knn_ws (B*n*3 + 1) i32 (the last int is
+ * the "index beyond the fast-sincos range" flag), idx_ws (B*n*n*4) f32. */
 int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term, const float* Wd, const float* bd,
                         const float* Wa, const float* ba, float sigma_d, float factor_a, int angle_k, int hidden,
                         int* knn_ws, float* idx_ws, float* out, void* stream);
@@ -89,14 +90,18 @@ int sam6d_geo_embedding(const float* points, int B, int n, const float* div_term
 int sam6d_geo_indices(const float* points, int B, int n, float sigma_d, float factor_a, int angle_k, int* knn_ws,
                       float* idx_ws, void* stream);
 int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, const float* Wd, const float* bd,
-                    const float* Wa, const float* ba, int hidden, float* out, void* stream);
+                    const float* Wa, const float* ba, int hidden, const int* flag, int only_if_large, float* out,
+                    void* stream);
 
 /* fp16 x3 split-precision form of sam6d_geo_embed (same call site, PEM/model/transformer.py:343-363): w_packed =
- * [8][2][256][64] halves = per 32-wide K chunk, per matrix (proj_d, proj_a), per output column: 32 hi | 32 lo halves of
- * weight*1024, produced with sam6d_split_f16 (x -> fp16(x*scale), fp16(x*scale - hi)) at weight-load time. */
+ * [16][2][256][32] halves = per 16-wide K chunk, per matrix (proj_d, proj_a), per output column: 16 hi | 16 lo halves of
+ * weight*1024, produced with sam6d_split_f16 (x -> fp16(x*scale), fp16(x*scale - hi)) at weight-load time.
+ * `flag` = the last int of knn_ws written by sam6d_geo_indices: when an embedding index exceeds the range of the
+ * branch-free sincos (1e5; never for radius-normalised clouds) the h3 kernel returns at once and a following
+ * sam6d_geo_embed(..., flag, only_if_large = 1, ...) launch produces the result with the library sincosf. */
 int sam6d_split_f16(const float* x, long n, float scale, void* hi, void* lo, void* stream);
 int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
-                       const float* ba, int hidden, float* out, void* stream);
+                       const float* ba, int hidden, const int* flag, float* out, void* stream);
 
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).

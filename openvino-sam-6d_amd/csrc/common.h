@@ -88,12 +88,9 @@ __device__ __forceinline__ float pdist3(float x0, float x1, float x2, float sx, 
 // sin and cos of the same fp32 argument, <= 1.5 ulp each for |x| < 1e5 (checked against fp64 over [0, 1000], the range of
 // the sinusoidal-embedding arguments: indices up to ~870 times frequencies <= 1): three-term Cody-Waite reduction by
 // pi/2 with fma, degree-9 / degree-8 minimax polynomials on [-pi/4, pi/4], quadrant fix-up.  ~30 VALU instructions,
-// branch-free; larger arguments take the library path.
+// branch-free.  The caller guarantees the range (geo.hip routes clouds with larger indices to the sincosf kernel).
+#define SAM6D_FAST_SINCOS_LIMIT 1.0e5f
 __device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
-  if (!(fabsf(x) < 1.0e5f)) {
-    sincosf(x, sn, cs);
-    return;
-  }
   const float j = rintf(x * 0.636619747f);
   float a = fmaf(j, -1.57079601e+00f, x);
   a = fmaf(j, -3.13916473e-07f, a);

@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // one wave per (b,i); n <= 256 (4 candidates per lane).  4 rounds of wave arg-min on (bits(dist), index).
 __global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ pts, int n, int k, int* __restrict__ knn,
                                                       long total) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) knn[total * k] = 0;  // max |index| flag, raised by geo_index_kernel
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= total) return;
   const int lane = threadIdx.x & 63;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ 
 // idx4[(b,i,j)] = {d_idx, a_idx[0..2]}  (k == 3)
 __global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
                                                         float sigma_d, float factor_a, float4* __restrict__ idx4,
-                                                        long total) {
+                                                        long total, int* __restrict__ maxflag) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int j = (int)(e % n);
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict_
     out[r + 1] = atan2f(s, c) * factor_a;
   }
   idx4[e] = make_float4(out[0], out[1], out[2], out[3]);
+  // embedding arguments are index * omega with omega <= 1: remember when an index leaves the range of the branch-free
+  // sincos (never for radius-normalised clouds: the largest index is the bg-point distance, ~870)
+  const float m = fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3])));
+  if (!(m < SAM6D_FAST_SINCOS_LIMIT)) atomicMax(maxflag, 1);
 }
 
 // ---------------------------------------------------------------------------------------------- 3. embedding
@@ -101,7 +106,9 @@ __global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict_
 __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
                                                            const float* __restrict__ Wd, const float* __restrict__ bd,
                                                            const float* __restrict__ Wa, const float* __restrict__ ba,
-                                                           float* __restrict__ out, long total) {
+                                                           float* __restrict__ out, long total,
+                                                           const int* __restrict__ maxflag, int only_if_large) {
+  if (only_if_large && *maxflag == 0) return;  // fallback launch behind the fp16x3 kernel: nothing to do
   __shared__ float As[4 * GE_P * GE_LD];       // 128 rows
   __shared__ float Bs[2 * 256 * GE_LD];        // [mat][col][k]
   __shared__ float xs[4 * GE_P];               // embedding index of each generated row
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float om = xrow * div_term[(k0 >> 1) + gf0 + u];
-      fast_sincosf(om, &sv[u], &cv[u]);
+      sincosf(om, &sv[u], &cv[u]);
     }
     __syncthreads();  // previous chunk consumed
 #pragma unroll
@@ -195,22 +202,26 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
 // Same contraction on v_mfma_f32_32x32x16_f16 with split operands (gemm.hip explains the arithmetic): 64 pairs
 // (256 generated rows) per workgroup of 8 waves; wave (ph, cq) owns pairs [32 ph, +32) x columns [64 cq, +64) for all
 // four row groups, so the max over the 3 angular rows and the final add stay in registers.  proj_d / proj_a arrive
-// pre-split and pre-tiled: Wp[kc][mat][col][64] = 32 hi halves | 32 lo halves of (W * 1024)[col][32 kc .. +32]
+// pre-split and pre-tiled: Wp[kc][mat][col][32] = 16 hi halves | 16 lo halves of (W * 1024)[col][16 kc .. +16]
 // (sam6d_split_f16 + a host-side re-tiling at weight-load time); 2^-10 is undone in the epilogue (exact).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define GH_P 64
-#define GH_LD 40
-#define GH_LDS_BYTES ((4 * GH_P * GH_LD * 2 + 2 * 256 * GH_LD * 2) * 2 + 4 * GH_P * 4)
+#define GH_BK 16
+#define GH_LD 24  // halves per LDS row (48 B): 16 consecutive rows fall on 16 different 16-byte slots of the bank row
+#define GH_LDS_BYTES ((4 * GH_P * GH_LD * 2 + 2 * 256 * GH_LD * 2) * 2 + 4 * GH_P * 4 + 128 * 4)
 
 __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
                                                            const _Float16* __restrict__ Wp, const float* __restrict__ bd,
-                                                           const float* __restrict__ ba, float* __restrict__ out, long total) {
+                                                           const float* __restrict__ ba, float* __restrict__ out, long total,
+                                                           const int* __restrict__ maxflag) {
+  if (*maxflag != 0) return;  // an index beyond the fast sincos range: the exact kernel launched next handles the call
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][40]
+  _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][24]
   _Float16* Al = Ah + 4 * GH_P * GH_LD;
-  _Float16* Bh = Al + 4 * GH_P * GH_LD;                 // [2*256][40]
+  _Float16* Bh = Al + 4 * GH_P * GH_LD;                 // [2*256][24]
   _Float16* Bl = Bh + 2 * 256 * GH_LD;
   float* xs = reinterpret_cast<float*>(Bl + 2 * 256 * GH_LD);  // [4][64]
+  float* om = xs + 4 * GH_P;                                   // [128] frequencies (bit-identical copy of div_term)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long p0 = (long)blockIdx.x * GH_P;
   if (t < GH_P) {
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
     xs[2 * GH_P + t] = v.z;
     xs[3 * GH_P + t] = v.w;
   }
+  if (t >= 256 && t < 384) om[t - 256] = div_term[t - 256];
   f32x16 acc[4][2];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -228,66 +240,63 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.f;
   __syncthreads();
-  const int grow = t & 255, gf0 = (t >> 8) * 8;  // A generation: row, first of the 8 frequencies of this chunk
+  const int grow = t & 255, gf0 = (t >> 8) * 4;  // A generation: row, first of the 4 frequencies of this chunk
   const float xrow = xs[grow];
   const int fr = lane & 31, fk = lane >> 5;
   const int ph = wave & 1, wn = (wave >> 1) * 64;
-  // software pipeline: the weights and the sinusoid rows of chunk kc+1 are produced (global loads + ~250 VALU per lane)
-  // after chunk kc's fragments are in LDS, in the same basic block as chunk kc's MFMAs, so the matrix pipe covers them
-  uint4 wv[8];
-  half8 ahi[2], alo[2];
+  // software pipeline: weights (4 x 16 B per lane) and sinusoid rows (4 sin/cos pairs per lane) of chunk kc+1 are
+  // produced right after chunk kc's fragments are visible in LDS, so their latency/VALU sits under chunk kc's MFMAs.
+  // 16-wide K chunks keep the prefetch at 24 registers: with 32-wide chunks the compiler spilled it to scratch and
+  // waited for every load at once (measured: MFMA pipe 17 % busy).
+  uint4 wv[4];
+  half8 ahi, alo;
   auto produce = [&](int kc) {
-    const uint4* src = reinterpret_cast<const uint4*>(Wp) + (size_t)kc * 4096;
+    const uint4* src = reinterpret_cast<const uint4*>(Wp) + (size_t)kc * 2048;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) wv[u] = src[t + 512 * u];
+    for (int u = 0; u < 4; ++u) wv[u] = src[t + 512 * u];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       float sv, cv;
-      fast_sincosf(xrow * div_term[kc * 16 + gf0 + u], &sv, &cv);
+      fast_sincosf(xrow * om[kc * 8 + gf0 + u], &sv, &cv);
       const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
-      ahi[u >> 2][(u & 3) * 2] = sh;
-      ahi[u >> 2][(u & 3) * 2 + 1] = ch;
-      alo[u >> 2][(u & 3) * 2] = (_Float16)(sv - (float)sh);
-      alo[u >> 2][(u & 3) * 2 + 1] = (_Float16)(cv - (float)ch);
+      ahi[2 * u] = sh;
+      ahi[2 * u + 1] = ch;
+      alo[2 * u] = (_Float16)(sv - (float)sh);
+      alo[2 * u + 1] = (_Float16)(cv - (float)ch);
     }
   };
   produce(0);
-  for (int kc = 0; kc < 8; ++kc) {
+  for (int kc = 0; kc < 256 / GH_BK; ++kc) {
     __syncthreads();  // previous chunk consumed
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int id = t + 512 * u;             // 16-byte unit: [mat*256+col][8 units: 4 hi | 4 lo]
-      const int rowc = id >> 3, part = id & 7;
-      _Float16* dst = ((part < 4) ? Bh : Bl) + rowc * GH_LD + (part & 3) * 8;
+    for (int u = 0; u < 4; ++u) {
+      const int id = t + 512 * u;             // 16-byte unit: [mat*256+col][4 units: 2 hi | 2 lo]
+      const int rowc = id >> 2, part = id & 3;
+      _Float16* dst = ((part < 2) ? Bh : Bl) + rowc * GH_LD + (part & 1) * 8;
       *reinterpret_cast<uint4*>(dst) = wv[u];
     }
-    *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi[0];
-    *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0 + 8]) = ahi[1];
-    *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo[0];
-    *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0 + 8]) = alo[1];
+    *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi;
+    *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo;
     __syncthreads();
-    if (kc + 1 < 8) produce(kc + 1);
+    if (kc + 1 < 256 / GH_BK) produce(kc + 1);
+    half8 bh[2][2], bl[2][2];  // [mat][col tile]
 #pragma unroll
-    for (int ks = 0; ks < 32; ks += 16) {
-      half8 bh[2][2], bl[2][2];  // [mat][col tile]
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int j = 0; j < 2; ++j) {
+        bh[mt][j] = *reinterpret_cast<const half8*>(&Bh[(mt * 256 + wn + 32 * j + fr) * GH_LD + 8 * fk]);
+        bl[mt][j] = *reinterpret_cast<const half8*>(&Bl[(mt * 256 + wn + 32 * j + fr) * GH_LD + 8 * fk]);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          bh[mt][j] = *reinterpret_cast<const half8*>(&Bh[(mt * 256 + wn + 32 * j + fr) * GH_LD + ks + 8 * fk]);
-          bl[mt][j] = *reinterpret_cast<const half8*>(&Bl[(mt * 256 + wn + 32 * j + fr) * GH_LD + ks + 8 * fk]);
-        }
+    for (int g = 0; g < 4; ++g) {
+      const half8 ah = *reinterpret_cast<const half8*>(&Ah[(g * GH_P + ph * 32 + fr) * GH_LD + 8 * fk]);
+      const half8 al = *reinterpret_cast<const half8*>(&Al[(g * GH_P + ph * 32 + fr) * GH_LD + 8 * fk]);
+      const int mt = g ? 1 : 0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const half8 ah = *reinterpret_cast<const half8*>(&Ah[(g * GH_P + ph * 32 + fr) * GH_LD + ks + 8 * fk]);
-        const half8 al = *reinterpret_cast<const half8*>(&Al[(g * GH_P + ph * 32 + fr) * GH_LD + ks + 8 * fk]);
-        const int mt = g ? 1 : 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt][j], acc[g][j], 0, 0, 0);
-          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt][j], acc[g][j], 0, 0, 0);
-          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt][j], acc[g][j], 0, 0, 0);
-        }
+      for (int j = 0; j < 2; ++j) {
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt][j], acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt][j], acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt][j], acc[g][j], 0, 0, 0);
       }
     }
   }
@@ -328,8 +337,8 @@ extern "C" int sam6d_split_f16(const float* x, long n, float scale, void* hi, vo
 }
 
 extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
-                                  const float* ba, int hidden, float* out, void* stream) {
-  SAM6D_REQUIRE(idx_ws && div_term && w_packed && bd && ba && out, "geo_embed_h3: null pointer");
+                                  const float* ba, int hidden, const int* flag, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && w_packed && bd && ba && out && flag, "geo_embed_h3: null pointer");
   SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed_h3: hidden_dim must be 256");
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed) & 15) == 0, "geo_embed_h3: idx_ws/weights must be 16-byte aligned");
   if (pairs == 0) return 0;
@@ -345,7 +354,7 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
   }
   hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES,
                      (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), div_term,
-                     reinterpret_cast<const _Float16*>(w_packed), bd, ba, out, pairs);
+                     reinterpret_cast<const _Float16*>(w_packed), bd, ba, out, pairs, flag);
   SAM6D_LAUNCH_CHECK("geo_embed_h3");
 }
 
@@ -366,18 +375,19 @@ extern "C" int sam6d_geo_indices(const float* points, int B, int n, float sigma_
   hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, points, n, angle_k, knn_ws, rows);
   SAM6D_LAUNCH_CHECK_CONT("geo_indices(knn)");
   hipLaunchKernelGGL(geo_index_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, points, knn_ws, n, sigma_d,
-                     factor_a, reinterpret_cast<float4*>(idx_ws), pairs);
+                     factor_a, reinterpret_cast<float4*>(idx_ws), pairs, knn_ws + rows * angle_k);
   SAM6D_LAUNCH_CHECK("geo_indices");
 }
 
 extern "C" int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, const float* Wd, const float* bd,
-                               const float* Wa, const float* ba, int hidden, float* out, void* stream) {
-  SAM6D_REQUIRE(idx_ws && div_term && Wd && bd && Wa && ba && out, "geo_embed: null pointer");
+                               const float* Wa, const float* ba, int hidden, const int* flag, int only_if_large, float* out,
+                               void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && Wd && bd && Wa && ba && out && flag, "geo_embed: null pointer");
   SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed: hidden_dim must be 256");
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embed: idx_ws/weights must be 16-byte aligned");
   if (pairs == 0) return 0;
   hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs);
+                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs, flag, only_if_large);
   SAM6D_LAUNCH_CHECK("geo_embed");
 }
 
@@ -386,5 +396,6 @@ extern "C" int sam6d_geo_embedding(const float* points, int B, int n, const floa
                                    int angle_k, int hidden, int* knn_ws, float* idx_ws, float* out, void* stream) {
   if (int rc = geo_check(B, n, angle_k, hidden)) return rc;
   if (int rc = sam6d_geo_indices(points, B, n, sigma_d, factor_a, angle_k, knn_ws, idx_ws, stream)) return rc;
-  return sam6d_geo_embed(idx_ws, (long)B * n * n, div_term, Wd, bd, Wa, ba, hidden, out, stream);
+  return sam6d_geo_embed(idx_ws, (long)B * n * n, div_term, Wd, bd, Wa, ba, hidden, knn_ws + (long)B * n * angle_k, 0, out,
+                         stream);
 }

@@ -216,22 +216,29 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     """points_bg (B,n,3) with the bg point prepended -> (B,n,n,256)   (PEM/model/transformer.py:343-363)."""
     B, n, _ = points_bg.shape
     out = _empty((B, n, n, C), points_bg)
-    knn = _empty((B, n, angle_k), points_bg, torch.int32)
+    knn = _empty((B * n * angle_k + 1,), points_bg, torch.int32)  # + the range flag
     idx = _empty((B, n, n, 4), points_bg)
+    flag = knn.data_ptr() + 4 * B * n * angle_k
     factor_a = 180.0 / (sigma_a * math.pi)
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
-    with _Timed("geo_embed_kernel"):
-        if _lib.load().sam6d_get_matmul_mode() == 1:
+    if _lib.load().sam6d_get_matmul_mode() == 1:
+        with _Timed("geo_embed_kernel"):
             _lib.call("sam6d_geo_embed_h3", _p(idx), B * n * n, _p(W.div_term), geo_packed(W).data_ptr(), _p(W.geo_d.b),
-                      _p(W.geo_a.b), C, _p(out), _s())
-        else:
+                      _p(W.geo_a.b), C, flag, _p(out), _s())
+    if _lib.load().sam6d_get_matmul_mode() == 1:
+        # indices beyond the fast sincos range (flag set on the device): this launch redoes the call exactly; otherwise
+        # it returns immediately
+        _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
+                  _p(W.geo_a.b), C, flag, 1, _p(out), _s())
+    else:
+        with _Timed("geo_embed_kernel"):
             _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
-                      _p(W.geo_a.b), C, _p(out), _s())
+                      _p(W.geo_a.b), C, flag, 0, _p(out), _s())
     return out
 
 
 def geo_packed(W):
-    """proj_d / proj_a split into fp16 hi/lo (scaled by 1024) and tiled [kc][mat][col][32 hi | 32 lo] for
+    """proj_d / proj_a split into fp16 hi/lo (scaled by 1024) and tiled [kc][mat][col][16 hi | 16 lo] for
     geo_embed_h3_kernel; built once per weight set.  The split is a HIP kernel, the re-tiling pure data movement."""
     pk = getattr(W, "_geo_pack", None)
     if pk is None:
@@ -239,8 +246,8 @@ def geo_packed(W):
         hi = torch.empty(both.shape, dtype=torch.float16, device=both.device)
         lo = torch.empty_like(hi)
         _lib.call("sam6d_split_f16", _p(both), both.numel(), 1024.0, hi.data_ptr(), lo.data_ptr(), _s())
-        t = lambda x: x.view(2, C, 8, 32).permute(2, 0, 1, 3)  # (kc, mat, col, 32)
-        pk = torch.cat([t(hi), t(lo)], dim=3).contiguous()     # (8, 2, 256, 64)
+        t = lambda x: x.view(2, C, 16, 16).permute(2, 0, 1, 3)  # (kc, mat, col, 16)
+        pk = torch.cat([t(hi), t(lo)], dim=3).contiguous()      # (16, 2, 256, 32)
         W._geo_pack = pk
     return pk
 

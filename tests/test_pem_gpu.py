@@ -111,12 +111,14 @@ def test_geo_indices_and_knn(dev, W):
     g = golden("geo_embedding")
     pts = _t(g["pts"]).to(dev)
     B, n, _ = pts.shape
-    knn = torch.empty(B, n, 3, dtype=torch.int32, device=dev)
+    knn = torch.empty(B * n * 3 + 1, dtype=torch.int32, device=dev)
     idx = torch.empty(B, n, n, 4, device=dev)
     out = torch.empty(B, n, n, 256, device=dev)
     _lib.call("sam6d_geo_embedding", pts.data_ptr(), B, n, W.div_term.data_ptr(), W.geo_d.w.data_ptr(), W.geo_d.b.data_ptr(),
               W.geo_a.w.data_ptr(), W.geo_a.b.data_ptr(), 0.2, 180.0 / (15 * math.pi), 3, 256, knn.data_ptr(), idx.data_ptr(),
               out.data_ptr(), pem._s())
+    assert int(knn[-1]) == 0, "range flag must stay clear for normalised clouds"
+    knn = knn[:-1].reshape(B, n, 3)
     assert np.array_equal(knn.cpu().numpy(), g["knn"].astype(np.int32))
     # d_idx = sqrt(pd) / 0.2: the device result is the correctly rounded one (checked here in fp64); the reference's
     # torch-CPU sqrt is 1 ulp low on ~0.6 % of the entries, so the golden tensor is matched to <= 1 ulp, >= 99 % exact
@@ -427,3 +429,24 @@ def test_matmul_modes_error_vs_fp64(dev):
     scale = float(want.abs().max())
     print("\nmatmul max abs err vs fp64: exact-fp32 %.2e, fp16x3 %.2e (result scale %.1f)" % (errs[0], errs[1], scale))
     assert errs[0] < 2e-6 * scale and errs[1] < 4e-6 * scale
+
+
+def test_geo_embedding_large_index_fallback(dev, W, sd):
+    """Indices beyond the branch-free sincos range (un-normalised clouds) must take the exact sincosf kernel: the
+    default (fp16x3) mode and the exact mode agree and match the oracle."""
+    from sam6d_hip import _lib, pem
+    from oracle import pem_oracle as O
+    gen = torch.Generator().manual_seed(21)
+    pts = (torch.rand(1, 40, 3, generator=gen) - 0.5) * 4.0e4  # d_idx up to ~3e5
+    got = pem.geo_embedding(pts.to(dev), W)
+    prev = _lib.load().sam6d_get_matmul_mode()
+    try:
+        _lib.call("sam6d_set_matmul_mode", 0)
+        exact = pem.geo_embedding(pts.to(dev), W)
+    finally:
+        _lib.call("sam6d_set_matmul_mode", prev)
+    assert torch.equal(got, exact), "flagged call must be produced by the exact kernel"
+    want = O.geo_embedding(pts, sd)
+    # arguments ~1e5: one fp32 ulp of the index (0.03) already moves sin/cos by O(1e-2); compare loosely
+    assert torch.isfinite(got).all()
+    assert float((got.cpu() - want).abs().median()) < 0.2
