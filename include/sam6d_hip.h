@@ -94,7 +94,7 @@ int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, cons
                     void* stream);
 
 /* fp16 x3 split-precision form of sam6d_geo_embed (same call site, PEM/model/transformer.py:343-363): w_packed =
- * [16][2][256][32] halves = per 16-wide K chunk, per matrix (proj_d, proj_a), per output column: 16 hi | 16 lo halves of
+ * [16][2][256][40] halves = per 16-wide K chunk, per matrix (proj_d, proj_a), per output column: 16 hi | 16 lo | 8 pad halves of
  * weight*1024, produced with sam6d_split_f16 (x -> fp16(x*scale), fp16(x*scale - hi)) at weight-load time.
  * `flag` = the last int of knn_ws written by sam6d_geo_indices: when an embedding index exceeds the range of the
  * branch-free sincos (1e5; never for radius-normalised clouds) the h3 kernel returns at once and a following

@@ -202,28 +202,41 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
 // Same contraction on v_mfma_f32_32x32x16_f16 with split operands (gemm.hip explains the arithmetic): 64 pairs
 // (256 generated rows) per workgroup of 8 waves; wave (ph, cq) owns pairs [32 ph, +32) x columns [64 cq, +64) for all
 // four row groups, so the max over the 3 angular rows and the final add stay in registers.  proj_d / proj_a arrive
-// pre-split and pre-tiled: Wp[kc][mat][col][32] = 16 hi halves | 16 lo halves of (W * 1024)[col][16 kc .. +16]
+// pre-split and pre-tiled: Wp[kc][mat][col][40 halves] = 16 hi | 16 lo | 8 pad halves of (W * 1024)[col][16 kc .. +16]
 // (sam6d_split_f16 + a host-side re-tiling at weight-load time); 2^-10 is undone in the epilogue (exact).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define GH_P 64
 #define GH_BK 16
-#define GH_LD 24  // halves per LDS row (48 B): 16 consecutive rows fall on 16 different 16-byte slots of the bank row
-#define GH_LDS_BYTES ((4 * GH_P * GH_LD * 2 + 2 * 256 * GH_LD * 2) * 2 + 4 * GH_P * 4 + 128 * 4)
+#define GH_LD 24                        // halves per A row in LDS (48 B)
+#define GH_BROW 80                      // bytes per weight row image: 16 hi halves | 16 lo halves | 16 B pad
+#define GH_BCHUNK (2 * 256 * GH_BROW)   // 40 960 B: one 16-wide K chunk of {proj_d, proj_a}
+#define GH_ABYTES (2 * 4 * GH_P * GH_LD * 2)
+#define GH_LDS_BYTES (GH_ABYTES + 2 * GH_BCHUNK + 4 * GH_P * 4 + 128 * 4)
 
 __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
-                                                           const _Float16* __restrict__ Wp, const float* __restrict__ bd,
+                                                           const unsigned char* __restrict__ Wp, const float* __restrict__ bd,
                                                            const float* __restrict__ ba, float* __restrict__ out, long total,
                                                            const int* __restrict__ maxflag) {
   if (*maxflag != 0) return;  // an index beyond the fast sincos range: the exact kernel launched next handles the call
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][24]
   _Float16* Al = Ah + 4 * GH_P * GH_LD;
-  _Float16* Bh = Al + 4 * GH_P * GH_LD;                 // [2*256][24]
-  _Float16* Bl = Bh + 2 * 256 * GH_LD;
-  float* xs = reinterpret_cast<float*>(Bl + 2 * 256 * GH_LD);  // [4][64]
-  float* om = xs + 4 * GH_P;                                   // [128] frequencies (bit-identical copy of div_term)
+  unsigned char* Bb = lds_raw + GH_ABYTES;               // 2 x [512 rows][80 B], filled by LDS-DMA
+  float* xs = reinterpret_cast<float*>(Bb + 2 * GH_BCHUNK);  // [4][64]
+  float* om = xs + 4 * GH_P;                                 // [128] frequencies (bit-identical copy of div_term)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long p0 = (long)blockIdx.x * GH_P;
+  // weights: the global image of a chunk IS the LDS image (rows of 80 B), so each wave copies 5 x 1 KiB pieces with
+  // global_load_lds_dwordx4 (no VGPRs, no ds_write); double-buffered, chunk kc+1 streams in under chunk kc's MFMAs
+  auto dma = [&](int kc) {
+    const unsigned char* src = Wp + (size_t)kc * GH_BCHUNK + (size_t)(wave * 5) * 1024 + lane * 16;
+    unsigned char* dst = Bb + (kc & 1) * GH_BCHUNK + (wave * 5) * 1024;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + i * 1024),
+                                       (void __attribute__((address_space(3)))*)(dst + i * 1024), 16, 0, 0);
+  };
+  dma(0);
   if (t < GH_P) {
     const float4 v = idx4[min(p0 + t, total - 1)];
     xs[0 * GH_P + t] = v.x;
@@ -244,16 +257,8 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   const float xrow = xs[grow];
   const int fr = lane & 31, fk = lane >> 5;
   const int ph = wave & 1, wn = (wave >> 1) * 64;
-  // software pipeline: weights (4 x 16 B per lane) and sinusoid rows (4 sin/cos pairs per lane) of chunk kc+1 are
-  // produced right after chunk kc's fragments are visible in LDS, so their latency/VALU sits under chunk kc's MFMAs.
-  // 16-wide K chunks keep the prefetch at 24 registers: with 32-wide chunks the compiler spilled it to scratch and
-  // waited for every load at once (measured: MFMA pipe 17 % busy).
-  uint4 wv[4];
   half8 ahi, alo;
-  auto produce = [&](int kc) {
-    const uint4* src = reinterpret_cast<const uint4*>(Wp) + (size_t)kc * 2048;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wv[u] = src[t + 512 * u];
+  auto produce = [&](int kc) {  // sinusoid rows of chunk kc, split into fp16 hi/lo, in registers
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float sv, cv;
@@ -267,26 +272,15 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   };
   produce(0);
   for (int kc = 0; kc < 256 / GH_BK; ++kc) {
-    __syncthreads();  // previous chunk consumed
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int id = t + 512 * u;             // 16-byte unit: [mat*256+col][4 units: 2 hi | 2 lo]
-      const int rowc = id >> 2, part = id & 3;
-      _Float16* dst = ((part < 2) ? Bh : Bl) + rowc * GH_LD + (part & 1) * 8;
-      *reinterpret_cast<uint4*>(dst) = wv[u];
-    }
+    __syncthreads();  // chunk kc-1 consumed; this wave's DMA pieces of chunk kc have landed (vmcnt(0) before the barrier)
     *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi;
     *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo;
-    __syncthreads();
-    if (kc + 1 < 256 / GH_BK) produce(kc + 1);
-    half8 bh[2][2], bl[2][2];  // [mat][col tile]
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[mt][j] = *reinterpret_cast<const half8*>(&Bh[(mt * 256 + wn + 32 * j + fr) * GH_LD + 8 * fk]);
-        bl[mt][j] = *reinterpret_cast<const half8*>(&Bl[(mt * 256 + wn + 32 * j + fr) * GH_LD + 8 * fk]);
-      }
+    __syncthreads();  // A rows and every wave's DMA pieces visible
+    if (kc + 1 < 256 / GH_BK) {
+      dma(kc + 1);
+      produce(kc + 1);
+    }
+    const unsigned char* Bc = Bb + (kc & 1) * GH_BCHUNK;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const half8 ah = *reinterpret_cast<const half8*>(&Ah[(g * GH_P + ph * 32 + fr) * GH_LD + 8 * fk]);
@@ -294,9 +288,12 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
       const int mt = g ? 1 : 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt][j], acc[g][j], 0, 0, 0);
-        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt][j], acc[g][j], 0, 0, 0);
-        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt][j], acc[g][j], 0, 0, 0);
+        const unsigned char* row = Bc + (size_t)(mt * 256 + wn + 32 * j + fr) * GH_BROW + 16 * fk;
+        const half8 bh = *reinterpret_cast<const half8*>(row);
+        const half8 bl = *reinterpret_cast<const half8*>(row + 32);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][j], 0, 0, 0);
       }
     }
   }
@@ -354,7 +351,7 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
   }
   hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES,
                      (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), div_term,
-                     reinterpret_cast<const _Float16*>(w_packed), bd, ba, out, pairs, flag);
+                     reinterpret_cast<const unsigned char*>(w_packed), bd, ba, out, pairs, flag);
   SAM6D_LAUNCH_CHECK("geo_embed_h3");
 }
 

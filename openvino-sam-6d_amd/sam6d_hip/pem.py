@@ -238,7 +238,7 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
 
 
 def geo_packed(W):
-    """proj_d / proj_a split into fp16 hi/lo (scaled by 1024) and tiled [kc][mat][col][16 hi | 16 lo] for
+    """proj_d / proj_a split into fp16 hi/lo (scaled by 1024) and tiled [kc][mat][col][16 hi | 16 lo | 8 pad] for
     geo_embed_h3_kernel; built once per weight set.  The split is a HIP kernel, the re-tiling pure data movement."""
     pk = getattr(W, "_geo_pack", None)
     if pk is None:
@@ -247,7 +247,8 @@ def geo_packed(W):
         lo = torch.empty_like(hi)
         _lib.call("sam6d_split_f16", _p(both), both.numel(), 1024.0, hi.data_ptr(), lo.data_ptr(), _s())
         t = lambda x: x.view(2, C, 16, 16).permute(2, 0, 1, 3)  # (kc, mat, col, 16)
-        pk = torch.cat([t(hi), t(lo)], dim=3).contiguous()      # (16, 2, 256, 32)
+        pad = torch.zeros(16, 2, C, 8, dtype=torch.float16, device=both.device)
+        pk = torch.cat([t(hi), t(lo), pad], dim=3).contiguous()  # (16, 2, 256, 40): the kernel's LDS row image (80 B)
         W._geo_pack = pk
     return pk
 
