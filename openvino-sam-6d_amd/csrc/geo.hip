@@ -258,29 +258,27 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   const int fr = lane & 31, fk = lane >> 5;
   const int ph = wave & 1, wn = (wave >> 1) * 64;
   half8 ahi, alo;
-  auto produce = [&](int kc) {  // sinusoid rows of chunk kc, split into fp16 hi/lo, in registers
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float sv, cv;
-      fast_sincosf(xrow * om[kc * 8 + gf0 + u], &sv, &cv);
-      const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
-      ahi[2 * u] = sh;
-      ahi[2 * u + 1] = ch;
-      alo[2 * u] = (_Float16)(sv - (float)sh);
-      alo[2 * u + 1] = (_Float16)(cv - (float)ch);
-    }
+  auto produce1 = [&](int kc, int u) {  // one sin/cos pair of chunk kc's sinusoid row, split into fp16 hi/lo
+    float sv, cv;
+    fast_sincosf(xrow * om[kc * 8 + gf0 + u], &sv, &cv);
+    const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
+    ahi[2 * u] = sh;
+    ahi[2 * u + 1] = ch;
+    alo[2 * u] = (_Float16)(sv - (float)sh);
+    alo[2 * u + 1] = (_Float16)(cv - (float)ch);
   };
-  produce(0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) produce1(0, u);
   for (int kc = 0; kc < 256 / GH_BK; ++kc) {
     __syncthreads();  // chunk kc-1 consumed; this wave's DMA pieces of chunk kc have landed (vmcnt(0) before the barrier)
     *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi;
     *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo;
     __syncthreads();  // A rows and every wave's DMA pieces visible
-    if (kc + 1 < 256 / GH_BK) {
-      dma(kc + 1);
-      produce(kc + 1);
-    }
+    const bool more = kc + 1 < 256 / GH_BK;
+    if (more) dma(kc + 1);
     const unsigned char* Bc = Bb + (kc & 1) * GH_BCHUNK;
+    // the ~45 VALU instructions of one sin/cos pair of the NEXT chunk are issued behind each row group's 6 MFMAs, so
+    // they run while the matrix pipe is busy (an MFMA holds the issue port for 8 of its 32 cycles)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const half8 ah = *reinterpret_cast<const half8*>(&Ah[(g * GH_P + ph * 32 + fr) * GH_LD + 8 * fk]);
@@ -295,6 +293,7 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
         acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[g][j], 0, 0, 0);
         acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g][j], 0, 0, 0);
       }
+      if (more) produce1(kc + 1, g);
     }
   }
   const float unscale = 1.0f / 1024.0f;
