@@ -42,28 +42,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   // Reduction plan per key row: the four per-head partial dots of a lane are folded with a transpose-butterfly
   // (xor 32 keeps two heads per half, xor 16 one head per quarter, then 4 steps inside the 16-lane group): 7 shuffles
   // instead of 24.  After it, lane group g = lane>>4 holds head g -- the same group that owns head g of q.k.
-  for (int j = wave; j < m; j += 4) {
-    const float4 kv = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
-    float se = (ql.x * kv.x + ql.y * kv.y) + (ql.z * kv.z + ql.w * kv.w);
-    if (RPE) {
-      const float4 ev = *reinterpret_cast<const float4*>(Eb + (size_t)j * 256 + lane * 4);
-      float sp[4];
+  // 4 key rows per wave iteration: the 8 independent 16-byte loads (E row + k row each) are issued back to back so
+  // that every wave keeps 8 KiB in flight instead of 2 KiB (the kernel is a pure HBM stream over E)
+  for (int j0 = wave * 4; j0 < m; j0 += 16) {
+    float4 kv[4], ev[4];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) sp[h] = (qf[h].x * ev.x + qf[h].y * ev.y) + (qf[h].z * ev.z + qf[h].w * ev.w);
-      const bool hi32 = lane & 32, hi16 = lane & 16;
-      // keep heads {0,1} in lanes 0-31 and {2,3} in lanes 32-63
-      const float s0 = hi32 ? sp[0] : sp[2], s1 = hi32 ? sp[1] : sp[3];  // what the partner half needs
-      const float k0 = hi32 ? sp[2] : sp[0], k1 = hi32 ? sp[3] : sp[1];
-      const float pa = k0 + __shfl_xor(s0, 32, 64), pb = k1 + __shfl_xor(s1, 32, 64);
-      // keep the even head of the pair in lanes with bit4 = 0, the odd one in lanes with bit4 = 1
-      const float send = hi16 ? pa : pb, keep = hi16 ? pb : pa;
-      se += keep + __shfl_xor(send, 16, 64);  // lane group (lane>>4) now carries head (lane>>4) of both terms
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, m - 1);
+      kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
+      if (RPE) ev[u] = *reinterpret_cast<const float4*>(Eb + (size_t)j * 256 + lane * 4);
     }
-    se += __shfl_xor(se, 1, 64);
-    se += __shfl_xor(se, 2, 64);
-    se += __shfl_xor(se, 4, 64);
-    se += __shfl_xor(se, 8, 64);
-    if ((lane & 15) == 0) s_s[lane >> 4][j] = se * scale;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      float se = (ql.x * kv[u].x + ql.y * kv[u].y) + (ql.z * kv[u].z + ql.w * kv[u].w);
+      if (RPE) {
+        float sp[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          sp[h] = (qf[h].x * ev[u].x + qf[h].y * ev[u].y) + (qf[h].z * ev[u].z + qf[h].w * ev[u].w);
+        const bool hi32 = lane & 32, hi16 = lane & 16;
+        // keep heads {0,1} in lanes 0-31 and {2,3} in lanes 32-63
+        const float s0 = hi32 ? sp[0] : sp[2], s1 = hi32 ? sp[1] : sp[3];  // what the partner half needs
+        const float k0 = hi32 ? sp[2] : sp[0], k1 = hi32 ? sp[3] : sp[1];
+        const float pa = k0 + __shfl_xor(s0, 32, 64), pb = k1 + __shfl_xor(s1, 32, 64);
+        // keep the even head of the pair in lanes with bit4 = 0, the odd one in lanes with bit4 = 1
+        const float send = hi16 ? pa : pb, keep = hi16 ? pb : pa;
+        se += keep + __shfl_xor(send, 16, 64);  // lane group (lane>>4) now carries head (lane>>4) of both terms
+      }
+      se += __shfl_xor(se, 1, 64);
+      se += __shfl_xor(se, 2, 64);
+      se += __shfl_xor(se, 4, 64);
+      se += __shfl_xor(se, 8, 64);
+      if ((lane & 15) == 0 && j < m) s_s[lane >> 4][j] = se * scale;
+    }
   }
   __syncthreads();
   {  // softmax of head `wave` over m (F.softmax: exp(x - max) / sum)

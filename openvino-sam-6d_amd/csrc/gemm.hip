@@ -119,6 +119,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
       const float cs = colscale ? colscale[col] : 1.f;
+      // all 16 residual loads first: C may alias `residual` (in-place add), so the compiler must not be left to
+      // interleave each load behind the previous store (that serialised 64 memory round trips per lane)
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        rv[r] = (residual && row < M) ? residual[(size_t)row * ldr + col] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
           if (divisor != 1.0f) v = v / divisor;
           v = colscale ? fmaf(v, cs, bv) : v + bv;
           if (act == 1) v = v > 0.f ? v : 0.f;
-          if (residual) v += residual[(size_t)row * ldr + col];
+          v += rv[r];
           C[(size_t)row * ldc + col] = v;
         }
       }
@@ -269,6 +277,14 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
       if (col >= N) continue;
       const float bv = bias ? bias[col] : 0.f;
       const float cs = colscale ? colscale[col] : 1.f;
+      // all 16 residual loads first: C may alias `residual` (in-place add), so the compiler must not be left to
+      // interleave each load behind the previous store (that serialised 64 memory round trips per lane)
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        rv[r] = (residual && row < M) ? residual[(size_t)row * ldr + col] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
           if (divisor != 1.0f) v = v / divisor;
           v = colscale ? fmaf(v, cs, bv) : v + bv;
           if (act == 1) v = v > 0.f ? v : 0.f;
-          if (residual) v += residual[(size_t)row * ldr + col];
+          v += rv[r];
           C[(size_t)row * ldc + col] = v;
         }
       }
