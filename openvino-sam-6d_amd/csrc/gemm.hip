@@ -169,13 +169,14 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
-                                                         long sC, long sR, float divisor, int act) {
+                                                         long sC, long sR, float divisor, int act, int wide) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RA = BM / 32, RB = BN / 32;  // float4 staging loads per thread (32 rows x 8 float4 per pass)
-  __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * H_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Al[BM * H_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Bh[BN * H_LD];
-  __shared__ __attribute__((aligned(16))) _Float16 Bl[BN * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * H_LD];  // also the epilogue's transpose slabs
+  _Float16* Ah = smem;
+  _Float16* Al = Ah + BM * H_LD;
+  _Float16* Bh = Al + BM * H_LD;
+  _Float16* Bl = Bh + BN * H_LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bz = blockIdx.z;
   A += (size_t)bz * sA;
@@ -269,6 +270,59 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
         }
     }
   }
+  if (wide) {
+    // Wide epilogue: each wave transposes its 32 x (BN/2) accumulator slab through LDS so that a lane owns 4
+    // consecutive columns of one row: residual loads and C stores become 16-byte accesses of full 128/256-byte row
+    // segments (the accumulator layout itself gives 4-byte accesses, 4x the instructions and half-used lines).
+    constexpr int WC = BN / 2, SLD = WC + 4, LPR = WC / 4, RPP = 64 / LPR, NP = 32 / RPP;
+    __syncthreads();  // every wave is done reading operand fragments: the staging buffers can be reused
+    float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
+    const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
+    const int col = n0 + wn + c4;
+    float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (col < N) {
+      if (bias) bv4 = *reinterpret_cast<const float4*>(bias + col);
+      if (colscale) cs4 = *reinterpret_cast<const float4*>(colscale + col);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * fk) * SLD + j * 32 + fr] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4 rv[NP];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int row = m0 + wm + i * 32 + it * RPP + rr0;
+        rv[it] = (residual && row < M && col < N) ? *reinterpret_cast<const float4*>(residual + (size_t)row * ldr + col)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int rr = it * RPP + rr0;
+        const int row = m0 + wm + i * 32 + rr;
+        if (row < M && col < N) {
+          float4 v = *reinterpret_cast<const float4*>(&slab[rr * SLD + c4]);
+          float e[4] = {v.x, v.y, v.z, v.w};
+          const float bb[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, cc[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+          const float rz[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float x = e[q];
+            if (divisor != 1.0f) x = x / divisor;
+            x = colscale ? fmaf(x, cc[q], bb[q]) : x + bb[q];
+            if (act == 1) x = x > 0.f ? x : 0.f;
+            e[q] = x + rz[q];
+          }
+          *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // slab is rewritten by the next row tile
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -323,11 +377,16 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
   dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64), batch);  // M tiles on x (2^31 limit)
   SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
   hipStream_t st = (hipStream_t)stream;
-#define GEMM_LAUNCH(KERNEL)                                                                                              \
+#define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
-                     sC, sR, divisor, act)
+                     sC, sR, divisor, act, ##__VA_ARGS__)
   if (g_matmul_mode == 1 && K >= 32) {
-    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>));
+    // 16-byte epilogue accesses need 4-float alignment of every row start and of the per-column vectors
+    const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (((size_t)C) & 15) == 0 &&
+                      (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (((size_t)residual) & 15) == 0)) &&
+                      (!bias || (((size_t)bias) & 15) == 0) && (!colscale || (((size_t)colscale) & 15) == 0))
+                         ? 1 : 0;
+    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>), wide); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>), wide);
   } else {
     if (big) GEMM_LAUNCH((gemm_nt_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_kernel<64, 64>));
   }

@@ -127,6 +127,159 @@ __global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_kernel(
   }
 }
 
+// ===============================================================================================================
+// fp16 x3 split-precision form of the same fused kernel (default matmul mode): layer 1 (K = 6) stays on the exact
+// fp32 MFMA (3 instructions), layers 2 and 3 run on v_mfma_f32_32x32x16_f16 with hi/lo operands (gemm.hip explains
+// the arithmetic): 12 + 48 MFMAs of 32 cycles per 32-neighbour tile instead of 32 + 128 of 64 cycles.  Hidden
+// activations are split into fp16 hi/lo when they are written to the wave's LDS slab (h1 aliases h2: it is dead once
+// layer 2's products have been issued); weights are split once per workgroup while they are staged.
+// ===============================================================================================================
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+#define PH_L2 40   // halves per row of the K=32 images (80 B)
+#define PH_L3 72   // halves per row of the K=64 images (144 B = 9 x 16 B: 16 consecutive rows hit 16 different slots)
+#define PH_WBYTES (32 * 7 * 4 + 448 * 4 + 2 * 64 * PH_L2 * 2 + 2 * 128 * PH_L3 * 2)
+#define PH_HBYTES (2 * 32 * PH_L3 * 2)
+
+__global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_h3_kernel(
+    const float* __restrict__ pts, const int* __restrict__ idx, int N, int S, long total, const float* __restrict__ W1,
+    const float* __restrict__ sc1, const float* __restrict__ sh1, const float* __restrict__ W2, const float* __restrict__ sc2,
+    const float* __restrict__ sh2, const float* __restrict__ W3, const float* __restrict__ sc3, const float* __restrict__ sh3,
+    float* __restrict__ out, long ldo, int off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
+  float* w1s = reinterpret_cast<float*>(lraw);                  // [32][7] fp32
+  float* bn = w1s + 32 * 7;                                     // sc1 32 | sh1 32 | sc2 64 | sh2 64 | sc3 128 | sh3 128
+  _Float16* w2h = reinterpret_cast<_Float16*>(bn + 448);        // [64][40]
+  _Float16* w2l = w2h + 64 * PH_L2;
+  _Float16* w3h = w2l + 64 * PH_L2;                             // [128][72]
+  _Float16* w3l = w3h + 128 * PH_L3;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  _Float16* hh = reinterpret_cast<_Float16*>(lraw + PH_WBYTES + wave * PH_HBYTES);  // hi image [32][72] (h1 uses [32][40])
+  _Float16* hl = hh + 32 * PH_L3;                                                    // lo image
+  for (int e = t; e < 32 * 6; e += PM_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e];
+  for (int e = t; e < 64 * 32; e += PM_WAVES * 64) {
+    const float v = W2[e];
+    const _Float16 h = (_Float16)v;
+    w2h[(e >> 5) * PH_L2 + (e & 31)] = h;
+    w2l[(e >> 5) * PH_L2 + (e & 31)] = (_Float16)(v - (float)h);
+  }
+  for (int e = t; e < 128 * 64; e += PM_WAVES * 64) {
+    const float v = W3[e];
+    const _Float16 h = (_Float16)v;
+    w3h[(e >> 6) * PH_L3 + (e & 63)] = h;
+    w3l[(e >> 6) * PH_L3 + (e & 63)] = (_Float16)(v - (float)h);
+  }
+  if (t < 32) { bn[t] = sc1[t]; bn[32 + t] = sh1[t]; }
+  if (t < 64) { bn[64 + t] = sc2[t]; bn[128 + t] = sh2[t]; }
+  if (t < 128) { bn[192 + t] = sc3[t]; bn[320 + t] = sh3[t]; }
+  __syncthreads();
+  const int fr = lane & 31, fk = lane >> 5;
+  const int ntile = S >> 5;
+  for (int i = 0; i < PM_PPW; ++i) {
+    const long p = ((long)blockIdx.x * PM_WAVES + wave) * PM_PPW + i;
+    if (p >= total) break;
+    const long b = p / N;
+    const float* pb = pts + b * N * 3;
+    const float qx = pts[p * 3] + 0.00000001f, qy = pts[p * 3 + 1] + 0.00000001f, qz = pts[p * 3 + 2] + 0.00000001f;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = 0; tile < ntile; ++tile) {
+      const int nb = idx[p * S + tile * 32 + fr];
+      const bool ok = nb >= 0 && nb < N;
+      const float x = ok ? pb[nb * 3] : 0.f, y = ok ? pb[nb * 3 + 1] : 0.f, z = ok ? pb[nb * 3 + 2] : 0.f;
+      const float f0 = fk ? (y - qy) : (x - qx);
+      const float f1 = fk ? x : (z - qz);
+      const float f2 = fk ? z : y;
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, w1s[fr * 7 + 0 + fk], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, w1s[fr * 7 + 2 + fk], a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2, w1s[fr * 7 + 4 + fk], a1, 0, 0, 0);
+      {
+        const float s = bn[fr], h = bn[32 + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = fmaf(a1[r], s, h);
+          v = v > 0.f ? v : 0.f;
+          const _Float16 vh = (_Float16)v;
+          const int o = ((r & 3) + 8 * (r >> 2) + 4 * fk) * PH_L2 + fr;
+          hh[o] = vh;
+          hl[o] = (_Float16)(v - (float)vh);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- layer 2: K = 32 -> 2 k-steps of 16, 2 column tiles
+      f32x16 a2[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 32; ks += 16) {
+        const half8 ah = *reinterpret_cast<const half8*>(&hh[fr * PH_L2 + ks + 8 * fk]);
+        const half8 al = *reinterpret_cast<const half8*>(&hl[fr * PH_L2 + ks + 8 * fk]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const half8 bh = *reinterpret_cast<const half8*>(&w2h[(c * 32 + fr) * PH_L2 + ks + 8 * fk]);
+          const half8 bl = *reinterpret_cast<const half8*>(&w2l[(c * 32 + fr) * PH_L2 + ks + 8 * fk]);
+          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2[c], 0, 0, 0);
+          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a2[c], 0, 0, 0);
+          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a2[c], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // h1 image fully read (into registers) before h2 overwrites it
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float s = bn[64 + c * 32 + fr], h = bn[128 + c * 32 + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = fmaf(a2[c][r], s, h);
+          v = v > 0.f ? v : 0.f;
+          const _Float16 vh = (_Float16)v;
+          const int o = ((r & 3) + 8 * (r >> 2) + 4 * fk) * PH_L3 + c * 32 + fr;
+          hh[o] = vh;
+          hl[o] = (_Float16)(v - (float)vh);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- layer 3: K = 64 -> 4 k-steps, 4 column tiles
+      f32x16 a3[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a3[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 64; ks += 16) {
+        const half8 ah = *reinterpret_cast<const half8*>(&hh[fr * PH_L3 + ks + 8 * fk]);
+        const half8 al = *reinterpret_cast<const half8*>(&hl[fr * PH_L3 + ks + 8 * fk]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const half8 bh = *reinterpret_cast<const half8*>(&w3h[(c * 32 + fr) * PH_L3 + ks + 8 * fk]);
+          const half8 bl = *reinterpret_cast<const half8*>(&w3l[(c * 32 + fr) * PH_L3 + ks + 8 * fk]);
+          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a3[c], 0, 0, 0);
+          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a3[c], 0, 0, 0);
+          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a3[c], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float s = bn[192 + c * 32 + fr], h = bn[320 + c * 32 + fr];
+        float m = mx[c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaf(a3[c][r], s, h));
+        mx[c] = m;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float m = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
+      if (fk == 0) out[p * ldo + off + c * 32 + fr] = m;
+    }
+  }
+}
+
 extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
                                 const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
                                 const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream) {
@@ -134,20 +287,37 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
   SAM6D_REQUIRE(B >= 0 && N > 0 && S > 0 && (S & 31) == 0, "pe_mlp_max: nsample must be a multiple of 32 (got %d)", S);
   const long total = (long)B * N;
   if (total == 0) return 0;
-  const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-      return (int)e;
-    }
-    attr_set = true;
-  }
   const long per_block = PM_WAVES * PM_PPW;
-  hipLaunchKernelGGL(pe_mlp_max_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(PM_WAVES * 64), lds,
-                     (hipStream_t)stream, pts, idx, N, S, total, W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+  const dim3 grid((unsigned)((total + per_block - 1) / per_block));
+  if (sam6d_get_matmul_mode() == 1) {
+    const size_t lds = (size_t)PH_WBYTES + PM_WAVES * PH_HBYTES;
+    static bool attr_h3 = false;
+    if (!attr_h3) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_h3_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      attr_h3 = true;
+    }
+    hipLaunchKernelGGL(pe_mlp_max_h3_kernel, grid, dim3(PM_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, total, W1,
+                       sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+  } else {
+    const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(pe_mlp_max_kernel, grid, dim3(PM_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, total, W1, sc1,
+                       sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+  }
   SAM6D_LAUNCH_CHECK("pe_mlp_max");
 }
 
