@@ -8,8 +8,8 @@ with inputs resident in HBM when the timed region starts.  N>1: one process per 
 proposals (weak scaling, proposals are independent) and the ranks all-gather the 13 floats/proposal (R, t, score) over
 RCCL inside the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (geo_embed_kernel, fp32 MFMA), timed
-with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (the geometric-embedding contraction),
+timed with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
 algorithm, oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -29,6 +29,7 @@ import torch  # noqa: E402
 B_PER_GPU = 32
 GEO_FLOP_PER_CLOUD = 2.0 * 197 * 197 * 4 * 256 * 256  # 20.35 GFLOP: (d + 3 angular rows) x 256x256 per pair
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 
 
 def cpu_baseline(sd, nprop, threads):
@@ -56,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-proposals", type=int, default=2, help="proposals in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-proposals", type=int, default=1, help="proposals in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     args = ap.parse_args()
 
@@ -74,7 +75,7 @@ def main():
 
     import sam6d_hip
     sam6d_hip.require_lib()
-    from sam6d_hip import pem, synth
+    from sam6d_hip import _lib, pem, synth
     from sam6d_hip.parallel import gather_poses
 
     B = args.batch
@@ -115,6 +116,18 @@ def main():
         ms = sorted(a.elapsed_time(b) for a, b in ev)
         geo_ms = sum(ms) / max(1, len(ms))
         achieved = (2 * B * GEO_FLOP_PER_CLOUD) / (geo_ms * 1e-3) / 1e12 if ev else None
+        split = _lib.load().sam6d_get_matmul_mode() == 1
+        # fp16x3 split mode: every fp32-equivalent product costs 3 fp16 MFMA products, so the bound for ALGORITHMIC
+        # flops is the dense fp16 MFMA peak / 3; exact mode: the fp32 MFMA peak
+        peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+        roofline = {"bound": "mfma",
+                    "kernel": ("geo_embed_h3_kernel (v_mfma_f32_32x32x16_f16, fp16x3 split = 3 MFMA products per fp32 product)"
+                               if split else "geo_embed_kernel (v_mfma_f32_32x32x2_f32)") + ", 2B clouds per launch",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+                    "traffic": None, "launch_ms": geo_ms, "launches_timed": len(ms),
+                    "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9,
+                    "executed_mfma_tflops": (3.0 * achieved if split else achieved) if achieved else None,
+                    "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
         res = {
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -122,14 +135,14 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PEM batch=%d proposals/GPU, 2048 scene + 2048 model pts, 1024 CAD pts, random-init weights "
                                    "(SURVEY 8d config 2)" % B, "proposals_per_gpu": B, "parallelism": "proposal-sharded x%d, "
-                                   "RCCL all-gather of 13 floats/proposal" % world},
-            "roofline": {"bound": "mfma", "kernel": "geo_embed_kernel (fp32 MFMA 32x32x2, 2B clouds per launch)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": None,
-                         "launch_ms": geo_ms, "launches_timed": len(ms)},
+                                   "RCCL all-gather of 13 floats/proposal" % world,
+                       "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA"},
+            "roofline": roofline,
         }
-        if args.cpu_proposals > 0 and world >= 1:
-            threads = os.cpu_count() or 1
+        if args.cpu_proposals > 0 and world == 1:
+            # host cores for the baseline: the GPU box gives a 1-GPU job a share of 16 cores (more threads only
+            # oversubscribe the shared host: 256 threads ran the same port 20x slower)
+            threads = min(len(os.sched_getaffinity(0)), 16)
             v, cdt, (cR, ct, cs), cinp = cpu_baseline(sd, args.cpu_proposals, threads)
             res["cpu_baseline"] = {"value": v, "unit": "proposals/s", "cores": threads, "kind": "port",
                                    "sample": "%d proposals of the same generator (seed 1), one at a time, oracle/pem_oracle.py "
