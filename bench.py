@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-proposals", type=int, default=1, help="proposals in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-proposals", type=int, default=8, help="proposals in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     args = ap.parse_args()
 
