@@ -450,3 +450,34 @@ def test_geo_embedding_large_index_fallback(dev, W, sd):
     # arguments ~1e5: one fp32 ulp of the index (0.03) already moves sin/cos by O(1e-2); compare loosely
     assert torch.isfinite(got).all()
     assert float((got.cpu() - want).abs().median()) < 0.2
+
+
+def test_config5_shape_4096_points(dev, W, sd):
+    """BASELINE config 5's geometry (fine_npoint = 4096): the whole path at N = 4096 dense points, B = 1, against the CPU
+    oracle (fp32; the config's fp16 attention variant is a later round)."""
+    from sam6d_hip import pem, synth
+    from oracle import pem_oracle as O
+    inp = synth.kat_inputs(B=1, seed=9, n_dense=4096, n_model=1024)
+    d = _to(dev, inp)
+    R, t, s, aux = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W,
+                                 d["rand"], return_aux=True)
+    oR, ot, os_, oaux = O.pem_match(inp["dense_pm"], inp["dense_fm"], inp["dense_po"], inp["dense_fo"], inp["radius"],
+                                    inp["model"], sd, inp["rand"], return_aux=True)
+    assert torch.equal(aux["fps_idx_m"].cpu(), oaux["fps_idx_m"]) and torch.equal(aux["fps_idx_o"].cpu(), oaux["fps_idx_o"])
+    _close(aux["init_R"], oaux["init_R"], 1e-4, "coarse R"); _close(aux["init_t"], oaux["init_t"], 1e-4, "coarse t")
+    _close(R, oR, 1e-4, "R"); _close(t, ot, 1e-4, "t"); _close(s, os_, 1e-4, "score")
+
+
+def test_template_cloud_fps_210k(dev):
+    """FPS over the 42 x 5000 = 210 000-point template cloud of get_obj_feats -> 2048 samples, plus
+    the feature gather (PEM/model/feature_extraction.py:152-158), bit-exact vs the oracle."""
+    from sam6d_hip import pem
+    from oracle import pointops as P
+    gen = torch.Generator().manual_seed(31)
+    pts = (torch.rand(1, 210000, 3, generator=gen) - 0.5) * 0.3
+    feats = torch.randn(1, 210000, 8, generator=gen)
+    want = P.furthest_point_sampling(pts, 2048)
+    sp, sf, idx = pem.sample_pts_feats(pts.to(dev), feats.to(dev), 2048)
+    assert torch.equal(idx.cpu(), want)
+    assert torch.equal(sp.cpu(), torch.gather(pts, 1, want.long().unsqueeze(2).expand(1, 2048, 3)))
+    assert torch.equal(sf.cpu(), torch.gather(feats, 1, want.long().unsqueeze(2).expand(1, 2048, 8)))
