@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     for (int u = 0; u < 4; ++u) {
       const int j = min(j0 + u, m - 1);
       kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
-      if (RPE) ev[u] = *reinterpret_cast<const float4*>(Eb + (size_t)j * 256 + lane * 4);
+      // E is streamed once per layer (2.5 GB per launch): non-temporal, so it does not evict the L2-resident k/v rows
+      if (RPE) ev[u] = __builtin_nontemporal_load(reinterpret_cast<const float4*>(Eb + (size_t)j * 256 + lane * 4));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

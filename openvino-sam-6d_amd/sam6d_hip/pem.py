@@ -476,15 +476,28 @@ def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=Fal
     return out
 
 
-def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False):
-    """dp (2B,N,3), df (2B,N,256) stacked [scene; template]  (PEM/model/fine_point_matching.py:42-79, eval)."""
+def fine_static(dp, df, W, cfg):
+    """The part of FinePointMatching.forward that does not depend on the coarse pose: in_proj of both clouds' dense
+    features into the token buffer D (2B,N+1,256) with the bg token, and the positional encoding of the TEMPLATE cloud
+    (PEM/model/fine_point_matching.py:47-51).  pem_match issues it on a side stream, under the latency-bound coarse stage."""
     Bp, N, _ = dp.shape
     B = Bp // 2
-    pe_pts = _empty((Bp, N, 3), dp)
-    _lib.call("sam6d_rigid_inverse", _p(dp), _p(init_R), _p(init_t), B, N, _p(pe_pts), _s())  # p1_ = (p1 - t) @ R
-    _lib.call("sam6d_copy_f32", _p(dp, B * N * 3), _p(pe_pts, B * N * 3), B * N * 3, _s())   # p2 unchanged
     D = _tokens_with_bg(df, W.fine["in_proj"], W.fine["bg"])
-    positional_encoding_add(pe_pts, W, D, C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"],
+    positional_encoding_add(dp[B:], W, D, B * (N + 1) * C + C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"],
+                            cfg["pe_nsample1"], cfg["pe_nsample2"])
+    return D
+
+
+def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None):
+    """dp (2B,N,3), df (2B,N,256) stacked [scene; template]  (PEM/model/fine_point_matching.py:42-79, eval).
+    D: the result of fine_static() when the caller has already produced it."""
+    Bp, N, _ = dp.shape
+    B = Bp // 2
+    if D is None:
+        D = fine_static(dp, df, W, cfg)
+    p1 = _empty((B, N, 3), dp)
+    _lib.call("sam6d_rigid_inverse", _p(dp), _p(init_R), _p(init_t), B, N, _p(p1), _s())  # p1_ = (p1 - t) @ R
+    positional_encoding_add(p1, W, D, C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"],
                             cfg["pe_nsample2"])
     for blk in W.fine["blocks"]:
         D = sparse_to_dense_transformer(D, E, fps_idx, blk)
@@ -493,6 +506,16 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
     if return_aux:
         return R, t, score, dict(atten=att)
     return R, t, score
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0.1, nproposal1=6000, nproposal2=300,
@@ -511,9 +534,22 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     pb = _empty((2 * B, n + 1, 3), dp)
     _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * B, n, _p(pb), _s())
     E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip idle;
+    # the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs beside it
+    # on a second HIP stream and is joined before the fine transformer.
+    D = None
+    if cfg.get("overlap", True):
+        main = torch.cuda.current_stream()
+        side = _side_stream(dp.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            D = fine_static(dp, df, W, cfg)
+        D.record_stream(main)
     c = coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux)
     R0, t0 = c[0], c[1]
-    f = fine_point_matching(dp, df, E, idx, radius, model, R0, t0, W, cfg, return_aux)
+    if D is not None:
+        main.wait_stream(side)
+    f = fine_point_matching(dp, df, E, idx, radius, model, R0, t0, W, cfg, return_aux, D=D)
     if return_aux:
         return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:B], fps_idx_o=idx[B:],
                                       geo=E)
