@@ -16,6 +16,7 @@
 #include "common.h"
 #include "../../include/sam6d_hip.h"
 
+typedef float fx4 __attribute__((ext_vector_type(4)));
 #define AT_MAXM 256
 template <bool RPE>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
       const int j = min(j0 + u, m - 1);
       kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
       // E is streamed once per layer (2.5 GB per launch): non-temporal, so it does not evict the L2-resident k/v rows
-      if (RPE) ev[u] = __builtin_nontemporal_load(reinterpret_cast<const float4*>(Eb + (size_t)j * 256 + lane * 4));
+      if (RPE) {
+        const fx4 e = __builtin_nontemporal_load(reinterpret_cast<const fx4*>(Eb + (size_t)j * 256 + lane * 4));
+        ev[u] = make_float4(e.x, e.y, e.z, e.w);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -9,6 +9,7 @@ sequential cross-attention halves (PEM/model/transformer.py:520-521) are issued 
 Citations: PEM = SAM-6D/Pose_Estimation_Model in the reference.
 """
 import math
+import os
 
 import torch
 
@@ -538,7 +539,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     # the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs beside it
     # on a second HIP stream and is joined before the fine transformer.
     D = None
-    if cfg.get("overlap", True):
+    if cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1"):
         main = torch.cuda.current_stream()
         side = _side_stream(dp.device)
         side.wait_stream(main)
