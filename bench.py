@@ -120,11 +120,17 @@ def main():
         # fp16x3 split mode: every fp32-equivalent product costs 3 fp16 MFMA products, so the bound for ALGORITHMIC
         # flops is the dense fp16 MFMA peak / 3; exact mode: the fp32 MFMA peak
         peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+        traffic = None  # HBM bytes per launch from the PMC pass recorded under profiles/ (not measured live)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj["kernels"]["geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if split and B == B_PER_GPU else None
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma",
                     "kernel": ("geo_embed_h3_kernel (v_mfma_f32_32x32x16_f16, fp16x3 split = 3 MFMA products per fp32 product)"
                                if split else "geo_embed_kernel (v_mfma_f32_32x32x2_f32)") + ", 2B clouds per launch",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                    "traffic": None, "launch_ms": geo_ms, "launches_timed": len(ms),
+                    "traffic": traffic, "launch_ms": geo_ms, "launches_timed": len(ms),
                     "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9,
                     "executed_mfma_tflops": (3.0 * achieved if split else achieved) if achieved else None,
                     "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
