@@ -79,6 +79,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
         fn.restype = c_i
+    mode = os.environ.get("SAM6D_MATMUL_MODE")  # 0 = exact fp32 MFMA, 1 = fp16x3 split (library default)
+    if mode is not None:
+        if lib.sam6d_set_matmul_mode(int(mode)) != 0:
+            raise RuntimeError("SAM6D_MATMUL_MODE=%s: %s" % (mode, lib.sam6d_last_error().decode()))
     _lib = lib
     return lib
 
