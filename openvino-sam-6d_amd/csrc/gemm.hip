@@ -203,10 +203,8 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk;
   const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
 
-  // two register sets: the tiles of K chunks k+1 AND k+2 are in flight while chunk k is multiplied (the 197-token
-  // GEMMs are a chain of only 8-16 chunks, so one chunk of prefetch left the global latency exposed on every step)
-  float4 va0[RA], vb0[RB], va1[RA], vb1[RB];
-  auto fetch = [&](int k0, float4 (&va)[RA], float4 (&vb)[RB]) {
+  float4 va[RA], vb[RB];
+  auto fetch = [&](int k0) {
     if (vec && k0 + H_BK <= K) {
 #pragma unroll
       for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
@@ -230,7 +228,8 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   };
 
   const int fr = lane & 31, fk = lane >> 5;
-  auto stage = [&](const float4 (&va)[RA], const float4 (&vb)[RB]) {
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += H_BK) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < RA; ++u) {
@@ -247,8 +246,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
       *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
     }
     __syncthreads();
-  };
-  auto multiply = [&]() {
+    if (k0 + H_BK < K) fetch(k0 + H_BK);
 #pragma unroll
     for (int ks = 0; ks < H_BK; ks += 16) {
       half8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -270,18 +268,6 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-    }
-  };
-  fetch(0, va0, vb0);
-  if (H_BK < K) fetch(H_BK, va1, vb1);
-  for (int k0 = 0; k0 < K; k0 += 2 * H_BK) {
-    stage(va0, vb0);
-    if (k0 + 2 * H_BK < K) fetch(k0 + 2 * H_BK, va0, vb0);
-    multiply();
-    if (k0 + H_BK < K) {
-      stage(va1, vb1);
-      if (k0 + 3 * H_BK < K) fetch(k0 + 3 * H_BK, va1, vb1);
-      multiply();
     }
   }
   if (wide) {
