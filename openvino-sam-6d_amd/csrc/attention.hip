@@ -7,123 +7,109 @@
 // proj_p is folded into the query: q_h.(W_p E + b_p)_h = (W_p,h^T q_h).E + q_h.b_p,h.  The second term
 // does not depend on m and cancels in the softmax, so it is dropped; qp[n,h,:] = W_p,h^T q_h (4 x 256 per token) is
 // produced by the GEMM kernel.  Executed flops per layer fall from 5.09 GFLOP to 0.08 GFLOP per proposal and the
-// RPE kernel becomes an HBM stream over E (39.7 MB per proposal, read once per layer).
+// kernel becomes a pure HBM stream over E (39.7 MB per proposal, read once per layer).
 //
-// One workgroup = AT_Q consecutive query tokens of one cloud, 4 waves.  Every key/value row fetched from L2 is used for
-// AT_Q queries (the one-query form moved 400 KB of k/v per query through L2: 22 TB/s aggregate, the L2 limit).
-//   Phase 1: waves stride over the key rows; a lane owns 4 channels (16-byte loads, a 1 KiB row per wave-instruction).
-//            q.k : AT_Q partial dots per lane, reduced inside the 16-lane head group by a transpose butterfly.
-//            qp.E: the query's own embedding row (streamed, non-temporal), 4 per-head partial dots per lane, folded
-//                  with a transpose butterfly across the wave (xor 32, xor 16) and then inside the head group.
-//   Phase 2: softmax over the keys in LDS, one (query, head) row per wave at a time (F.softmax: exp(x-max)/sum).
-//   Phase 3: thread (h,c) accumulates sum_m p[q][h][m] v[m,h,c] for the AT_Q queries from one coalesced read of v.
+// One workgroup per (b, n) query token, 4 waves.  Phase 1: the 197 embedding rows of that token are streamed with
+// 16-byte lanes (one 1 KiB row per wave-instruction, fully coalesced), each row reduced against the 4 folded queries
+// by a wave butterfly.  Phase 2: per-head softmax in LDS (one wave per head).  Phase 3: thread (h,c) accumulates
+// sum_m p[h,m] v[m,h,c] with coalesced reads of v rows (L2-resident: 201 KB per proposal).
 #include "common.h"
 #include "../../include/sam6d_hip.h"
 
 typedef float fx4 __attribute__((ext_vector_type(4)));
 #define AT_MAXM 256
-#define AT_Q 4
-
-__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
-
 template <bool RPE>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ qp,
                                                         const float* __restrict__ E, float* __restrict__ out, int n,
                                                         int m, long ldq, long ldk, long ldv, long ldo, long sq, long sk,
                                                         long sv, long so, float scale) {
-  __shared__ float s_s[AT_Q][4][AT_MAXM];
-  const int b = blockIdx.y, i0 = blockIdx.x * AT_Q;
+  __shared__ float s_s[4][AT_MAXM];
+  __shared__ float s_q[256];
+  const int b = blockIdx.y, i = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int nq = min(AT_Q, n - i0);  // queries handled by this workgroup (the last one may be partial)
-  float4 ql[AT_Q];                   // lane's 4 channels of each query (head = lane >> 4)
-  float4 qf[AT_Q][4];                // RPE: folded queries, [query][head]
+  const float* qrow = q + (size_t)b * sq + (size_t)i * ldq;
+  s_q[t] = qrow[t];
+  float4 qf[4];
+  if (RPE) {
+    const float* qpr = qp + ((size_t)b * n + i) * 1024;
 #pragma unroll
-  for (int u = 0; u < AT_Q; ++u) {
-    const int i = min(i0 + u, n - 1);
-    ql[u] = *reinterpret_cast<const float4*>(q + (size_t)b * sq + (size_t)i * ldq + lane * 4);
-    if (RPE) {
-      const float* qpr = qp + ((size_t)b * n + i) * 1024;
-#pragma unroll
-      for (int h = 0; h < 4; ++h) qf[u][h] = *reinterpret_cast<const float4*>(qpr + h * 256 + lane * 4);
-    }
+    for (int h = 0; h < 4; ++h) qf[h] = *reinterpret_cast<const float4*>(qpr + h * 256 + lane * 4);
   }
+  __syncthreads();
+  const float4 ql = *reinterpret_cast<const float4*>(&s_q[lane * 4]);  // lane covers head lane/16
+  const float* Eb = RPE ? E + ((size_t)b * n + i) * (size_t)m * 256 : nullptr;
   const float* kb = k + (size_t)b * sk;
-  const bool hi32 = lane & 32, hi16 = lane & 16, hi8 = lane & 8, hi4 = lane & 4;
-  for (int j = wave; j < m; j += 4) {
-    const float4 kv = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
-    float4 ev[AT_Q];
-    if (RPE) {
+  // Reduction plan per key row: the four per-head partial dots of a lane are folded with a transpose-butterfly
+  // (xor 32 keeps two heads per half, xor 16 one head per quarter, then 4 steps inside the 16-lane group): 7 shuffles
+  // instead of 24.  After it, lane group g = lane>>4 holds head g -- the same group that owns head g of q.k.
+  // 4 key rows per wave iteration: the 8 independent 16-byte loads (E row + k row each) are issued back to back so
+  // that every wave keeps 8 KiB in flight instead of 2 KiB (the kernel is a pure HBM stream over E)
+  for (int j0 = wave * 4; j0 < m; j0 += 16) {
+    float4 kv[4], ev[4];
 #pragma unroll
-      for (int u = 0; u < AT_Q; ++u) {
-        const int i = min(i0 + u, n - 1);
-        const fx4 e = __builtin_nontemporal_load(
-            reinterpret_cast<const fx4*>(E + (((size_t)b * n + i) * (size_t)m + j) * 256 + lane * 4));
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, m - 1);
+      kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)j * ldk + lane * 4);
+      // E is streamed once per layer (2.5 GB per launch): non-temporal, so it does not evict the L2-resident k/v rows
+      if (RPE) {
+        const fx4 e = __builtin_nontemporal_load(reinterpret_cast<const fx4*>(Eb + (size_t)j * 256 + lane * 4));
         ev[u] = make_float4(e.x, e.y, e.z, e.w);
       }
     }
-    // q.k partials of the AT_Q queries (per 16-lane head group) + RPE term folded to the same head group
-    float se[AT_Q];
 #pragma unroll
-    for (int u = 0; u < AT_Q; ++u) {
-      se[u] = dot4(ql[u], kv);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      float se = (ql.x * kv[u].x + ql.y * kv[u].y) + (ql.z * kv[u].z + ql.w * kv[u].w);
       if (RPE) {
         float sp[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) sp[h] = dot4(qf[u][h], ev[u]);
-        // transpose butterfly over the wave: heads {0,1} stay in lanes 0-31, {2,3} in 32-63; then even/odd head by bit 4
-        const float s0 = hi32 ? sp[0] : sp[2], s1 = hi32 ? sp[1] : sp[3];
+        for (int h = 0; h < 4; ++h)
+          sp[h] = (qf[h].x * ev[u].x + qf[h].y * ev[u].y) + (qf[h].z * ev[u].z + qf[h].w * ev[u].w);
+        const bool hi32 = lane & 32, hi16 = lane & 16;
+        // keep heads {0,1} in lanes 0-31 and {2,3} in lanes 32-63
+        const float s0 = hi32 ? sp[0] : sp[2], s1 = hi32 ? sp[1] : sp[3];  // what the partner half needs
         const float k0 = hi32 ? sp[2] : sp[0], k1 = hi32 ? sp[3] : sp[1];
         const float pa = k0 + __shfl_xor(s0, 32, 64), pb = k1 + __shfl_xor(s1, 32, 64);
+        // keep the even head of the pair in lanes with bit4 = 0, the odd one in lanes with bit4 = 1
         const float send = hi16 ? pa : pb, keep = hi16 ? pb : pa;
-        se[u] += keep + __shfl_xor(send, 16, 64);  // lane group (lane>>4) carries head (lane>>4) of both terms
+        se += keep + __shfl_xor(send, 16, 64);  // lane group (lane>>4) now carries head (lane>>4) of both terms
       }
-    }
-    // reduce the 4 query values inside each 16-lane group with a transpose butterfly: 2 + 1 + 2 shuffles instead of 16;
-    // afterwards the lanes with (lane & 3) == 0 hold the group sum of query 2*bit3 + bit2
-    {
-      const float a0 = hi8 ? se[0] : se[2], a1 = hi8 ? se[1] : se[3];  // the pair the partner keeps
-      const float b0 = hi8 ? se[2] : se[0], b1 = hi8 ? se[3] : se[1];
-      const float c0 = b0 + __shfl_xor(a0, 8, 64), c1 = b1 + __shfl_xor(a1, 8, 64);  // bit3=0: queries {0,1}; bit3=1: {2,3}
-      const float snd = hi4 ? c0 : c1, kp = hi4 ? c1 : c0;                            // bit2 selects the odd query
-      float r = kp + __shfl_xor(snd, 4, 64);
-      r += __shfl_xor(r, 1, 64);
-      r += __shfl_xor(r, 2, 64);
-      const int qi = ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-      if ((lane & 3) == 0 && qi < nq) s_s[qi][lane >> 4][j] = r * scale;
+      se += __shfl_xor(se, 1, 64);
+      se += __shfl_xor(se, 2, 64);
+      se += __shfl_xor(se, 4, 64);
+      se += __shfl_xor(se, 8, 64);
+      if ((lane & 15) == 0 && j < m) s_s[lane >> 4][j] = se * scale;
     }
   }
   __syncthreads();
-  for (int row = wave; row < nq * 4; row += 4) {  // softmax of one (query, head) row per wave
-    float* sr = s_s[row >> 2][row & 3];
+  {  // softmax of head `wave` over m (F.softmax: exp(x - max) / sum)
     float mx = -INFINITY;
-    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, sr[j]);
+    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, s_s[wave][j]);
     mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < m; j += 64) {
-      const float e = expf(sr[j] - mx);
-      sr[j] = e;
+      const float e = expf(s_s[wave][j] - mx);
+      s_s[wave][j] = e;
       sum += e;
     }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
-    for (int j = lane; j < m; j += 64) sr[j] *= inv;
+    for (int j = lane; j < m; j += 64) s_s[wave][j] *= inv;
   }
   __syncthreads();
   const float* vb = v + (size_t)b * sv + t;
-  const int h = t >> 6;
-  float acc[AT_Q];
-#pragma unroll
-  for (int u = 0; u < AT_Q; ++u) acc[u] = 0.f;
-  for (int j = 0; j < m; ++j) {
-    const float vv = vb[(size_t)j * ldv];
-#pragma unroll
-    for (int u = 0; u < AT_Q; ++u)
-      if (u < nq) acc[u] = fmaf(s_s[u][h][j], vv, acc[u]);
+  const float* pr = s_s[t >> 6];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = 0;
+  for (; j + 4 <= m; j += 4) {
+    a0 = fmaf(pr[j], vb[(size_t)j * ldv], a0);
+    a1 = fmaf(pr[j + 1], vb[(size_t)(j + 1) * ldv], a1);
+    a2 = fmaf(pr[j + 2], vb[(size_t)(j + 2) * ldv], a2);
+    a3 = fmaf(pr[j + 3], vb[(size_t)(j + 3) * ldv], a3);
   }
-#pragma unroll
-  for (int u = 0; u < AT_Q; ++u)
-    if (u < nq) out[(size_t)b * so + (size_t)(i0 + u) * ldo + t] = acc[u];
+  for (; j < m; ++j) a0 = fmaf(pr[j], vb[(size_t)j * ldv], a0);
+  out[(size_t)b * so + (size_t)i * ldo + t] = (a0 + a1) + (a2 + a3);
 }
 
 extern "C" int sam6d_attention(const float* q, const float* k, const float* v, const float* qp, const float* E, float* out,
@@ -136,7 +122,7 @@ extern "C" int sam6d_attention(const float* q, const float* k, const float* v, c
   SAM6D_REQUIRE(((ldq | ldk | ldv | ldo | sq | sk | sv | so) & 3) == 0, "attention: strides must be multiples of 4 floats");
   if (B == 0) return 0;
   const float scale = 0.125f;  // 1/sqrt(64): d_model 256, 4 heads (coarse_point_matching.py:24, fine_point_matching.py:31)
-  dim3 grid(cdiv(n, AT_Q), B);
+  dim3 grid(n, B);
   if (E)
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, qp, E, out, n, m, ldq,
                        ldk, ldv, ldo, sq, sk, sv, so, scale);
