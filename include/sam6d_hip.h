@@ -200,6 +200,19 @@ int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, float* iou, i
 int sam6d_ism_final_score(const float* sem, const float* appe, const float* geo, const float* vis, const int* sel, int Ns,
                           float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Rows SURVEY 8f marks "next" (callers either side of the path).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* replaces the radius normalisation of ViTEncoder.forward (PEM/model/feature_extraction.py:133-137):
+ * radius (B) = max_n |dense_po[b,n]|; po_out = dense_po / (radius + 1e-6); pm_out = pts / (radius + 1e-6). */
+int sam6d_radius_normalize(const float* dense_po, const float* pts, int B, int Npo, int Npm, float* radius, float* po_out,
+                           float* pm_out, void* stream);
+/* replaces the masked patch-descriptor post-processing of CustomDINOv2 (ISM/model/dinov2.py:265-269, 322-324):
+ * out = F.normalize(feats * [AvgPool2d(patch)(masks) > thresh], dim=-1); feats (N,P,D), masks (N,H,W) f32. */
+int sam6d_masked_patch_normalize(const float* feats, const float* masks, int N, int P, int D, int H, int W, int patch,
+                                 float thresh, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

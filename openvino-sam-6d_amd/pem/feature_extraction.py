@@ -11,6 +11,7 @@ import torch.nn as nn
 from torch.nn import functional as F
 
 from model_utils import get_chosen_pixel_feats, sample_pts_feats
+from sam6d_hip import pem as _pem
 
 
 class _Attn(nn.Module):
@@ -134,9 +135,7 @@ class ViTEncoder(nn.Module):
         if dense_po is None or dense_fo is None:
             raise ValueError('dense_po and dense_fo must be provided for export/inference')
         dense_fm = self.get_img_feats(rgb, rgb_choose)
-        radius = torch.norm(dense_po, dim=2).max(1)[0]
-        dense_pm = pts / (radius.reshape(-1, 1, 1) + 1e-6)
-        dense_po = dense_po / (radius.reshape(-1, 1, 1) + 1e-6)
+        dense_pm, dense_po, radius = _pem.radius_normalize(pts, dense_po)  # feature_extraction.py:133-137, on the GPU
         return dense_pm, dense_fm, dense_po, dense_fo, radius
 
     def get_img_feats(self, img, choose):

@@ -55,6 +55,8 @@ SIGNATURES = {
     "sam6d_ism_project": [c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    "sam6d_radius_normalize": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "sam6d_masked_patch_normalize": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
 }
 

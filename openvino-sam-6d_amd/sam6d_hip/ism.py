@@ -92,3 +92,20 @@ def final_score(sem, appe, geo, vis):
     g = geo if torch.is_tensor(geo) else None
     _lib.call("sam6d_ism_final_score", _p(sem.contiguous()), _p(appe), _p(g), _p(vis), None, Ns, _p(out), _s())
     return out
+
+
+def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thresh=0.5):
+    """CustomDINOv2's descriptor post-processing (ISM/model/dinov2.py:265-269, 322-324): zero the patches whose mask
+    coverage (AvgPool2d(patch_size)) is <= validpatch_thresh and L2-normalise the rest.  patch_features (N,P,D),
+    masks (N,H,W) -> (N,P,D)."""
+    N, P, D = patch_features.shape
+    H, W = masks.shape[1], masks.shape[2]
+    from .ops import _chk
+    f = patch_features.contiguous()
+    m = masks.to(torch.float32).contiguous()
+    _chk(f, "patch_features", torch.float32, 3)
+    _chk(m, "masks", torch.float32, 3)
+    out = _empty((N, P, D), f)
+    _lib.call("sam6d_masked_patch_normalize", _p(f), _p(m), N, P, D, H, W, int(patch_size), float(validpatch_thresh), _p(out),
+              _s())
+    return out

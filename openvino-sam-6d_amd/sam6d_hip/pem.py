@@ -557,6 +557,23 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     return f
 
 
+def radius_normalize(pts, dense_po):
+    """ViTEncoder.forward's radius normalisation (PEM/model/feature_extraction.py:133-137):
+    -> dense_pm (B,M,3), dense_po (B,N,3) both divided by (radius + 1e-6), radius (B,)."""
+    from .ops import _chk
+    pts = pts.contiguous()
+    dense_po = dense_po.contiguous()
+    _chk(pts, "pts", torch.float32, 3)
+    _chk(dense_po, "dense_po", torch.float32, 3)
+    B, N, _ = dense_po.shape
+    M = pts.shape[1]
+    radius = _empty((B,), pts)
+    po = _empty((B, N, 3), pts)
+    pm = _empty((B, M, 3), pts)
+    _lib.call("sam6d_radius_normalize", _p(dense_po), _p(pts), B, N, M, _p(radius), _p(po), _p(pm), _s())
+    return pm, po, radius
+
+
 def _cat0(a, b):
     """stack two (B,N,K) tensors along the batch -- a device copy, no arithmetic"""
     a = a.contiguous()

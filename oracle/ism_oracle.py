@@ -112,3 +112,10 @@ def geometric_score(image_uv, boxes, q_appe, ref, thred=0.5):
 def final_score(sem, appe, geo, vis):
     """ISM/model/detector.py:384 / ISM/run_inference_custom.py:255."""
     return (sem + appe + geo * vis) / (1 + 1 + vis)
+
+
+def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thresh=0.5):
+    """ISM/model/dinov2.py:265-269 / 322-324 (patch_kernel = nn.AvgPool2d(patch_size), :139-141)."""
+    keep = torch.nn.AvgPool2d(kernel_size=patch_size, stride=patch_size)(masks).flatten(-2) > validpatch_thresh
+    keep = keep.unsqueeze(-1).repeat(1, 1, patch_features.shape[-1])
+    return F.normalize(patch_features * keep, dim=-1)

@@ -364,6 +364,13 @@ def compute_fine_Rt(atten, pts1, pts2, model_pts, dis_thres=0.15):
     return R, t, score * mask.mean(1)
 
 
+# ---------------------------------------------------------------------------- next rows
+def radius_normalize(pts, dense_po):
+    """PEM/model/feature_extraction.py:133-137 (ViTEncoder.forward): radius = max point norm of the template cloud."""
+    radius = torch.norm(dense_po, dim=2).max(1)[0]
+    return pts / (radius.reshape(-1, 1, 1) + 1e-6), dense_po / (radius.reshape(-1, 1, 1) + 1e-6), radius
+
+
 # -------------------------------------------------------------------------------- modules (a14)
 def coarse_point_matching(p1, f1, g1, p2, f2, g2, radius, model, sd, rand, cfg=DEFAULT_CFG, faithful=False,
                           return_aux=False, p="coarse_point_matching"):
