@@ -17,6 +17,8 @@
 #ifndef SAM6D_HIP_H
 #define SAM6D_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -212,6 +214,28 @@ int sam6d_radius_normalize(const float* dense_po, const float* pts, int B, int N
  * out = F.normalize(feats * [AvgPool2d(patch)(masks) > thresh], dim=-1); feats (N,P,D), masks (N,H,W) f32. */
 int sam6d_masked_patch_normalize(const float* feats, const float* masks, int N, int P, int D, int H, int W, int patch,
                                  float thresh, float* out, void* stream);
+/* replaces get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) on a resident depth map (H,W) f32, metres:
+ * cloud (r1-r0, c1-c0, 3) for the crop bbox [rmin=r0, rmax=r1, cmin=c0, cmax=c1] (the whole image: 0,H,0,W). */
+int sam6d_depth_to_cloud(const float* depth, int H, int W, int r0, int r1, int c0, int c1, float fx, float fy, float cx,
+                         float cy, float* cloud, void* stream);
+/* replaces the test of Detections.remove_very_small_detections (ISM/model/utils.py:96-102): keep[i] (u8) =
+ * box_area(boxes[i]) / (H*W) > thr_box && masks[i].sum() / (H*W) > thr_mask; boxes (N,4) int64 xyxy, masks (N,H,W) f32.
+ * thr_box = min_box_size**2, thr_mask = min_mask_size. */
+int sam6d_detections_small_keep(const long long* boxes, const float* masks, int N, int H, int W, float thr_box,
+                                float thr_mask, unsigned char* keep, void* stream);
+/* boolean-mask indexing (ISM/model/utils.py:104-105): idx (N) i64 = positions of the non-zero keep bytes, count[0] = K. */
+int sam6d_mask_to_indices(const unsigned char* keep, int N, long long* idx, int* count, void* stream);
+/* replaces `getattr(self, key)[idxs]` of Detections.filter / apply_nms* (ISM/model/utils.py:105,119,126,190) for a
+ * tensor of any dtype: dst[j,:] = src[idx[j],:], rows of row_bytes bytes, idx (M) i64 (negative = from the end;
+ * out-of-range rows come back zero). */
+int sam6d_take_rows(const void* src, const long long* idx, long n_src, int M, long row_bytes, void* dst, void* stream);
+/* replaces torchvision.ops.nms as Detections.apply_nms (ISM/model/utils.py:121-124, group == NULL) and
+ * apply_nms_per_object_id (:107-117, group = object_ids) call it: boxes (N,4) f32 xyxy, scores (N) f32.
+ * keep_idx (N) i64 receives the surviving indices, ids ascending, score descending inside an id (stable); count[0] = K.
+ * ws: sam6d_nms_workspace_bytes(N) bytes of device memory. */
+size_t sam6d_nms_workspace_bytes(int N);
+int sam6d_nms(const float* boxes, const float* scores, const long long* group, int N, float thresh, long long* keep_idx,
+              int* count, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

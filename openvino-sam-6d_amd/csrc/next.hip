@@ -1,6 +1,7 @@
 // Rows SURVEY 8f marks "next" (the callers either side of the matching path), built to the same bar:
 //   radius normalisation of ViTEncoder.forward          PEM/model/feature_extraction.py:128-139
 //   masked patch-descriptor post-processing of DINOv2   ISM/model/dinov2.py:258-270, 308-326
+//   depth back-projection of get_test_data              PEM/utils/data_utils.py:92-110
 // (the third "next" item, FPS over the 210 000-point template cloud, is fps_big_kernel in pointops.hip)
 #include "common.h"
 #include "../../include/sam6d_hip.h"
@@ -87,4 +88,29 @@ extern "C" int sam6d_masked_patch_normalize(const float* feats, const float* mas
   hipLaunchKernelGGL(masked_patch_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, feats, masks, P,
                      D, H, W, patch, thresh, total, out);
   SAM6D_LAUNCH_CHECK("masked_patch_normalize");
+}
+
+// cloud[r, c, :] = ((c0 + c - cx) * z / fx, (r0 + r - cy) * z / fy, z), z = depth[r0 + r, c0 + c]   (fp32, numpy order:
+// subtract, multiply, divide -- get_point_cloud_from_depth with the crop bbox = [r0, r1, c0, c1])
+__global__ __launch_bounds__(256) void depth_to_cloud_kernel(const float* __restrict__ depth, int W, int r0, int c0, int h, int w,
+                                                             float fx, float fy, float cx, float cy, float* __restrict__ cloud) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)h * w) return;
+  const int r = (int)(e / w) + r0, c = (int)(e % w) + c0;
+  const float z = depth[(size_t)r * W + c];
+  cloud[e * 3 + 0] = ((float)c - cx) * z / fx;
+  cloud[e * 3 + 1] = ((float)r - cy) * z / fy;
+  cloud[e * 3 + 2] = z;
+}
+
+extern "C" int sam6d_depth_to_cloud(const float* depth, int H, int W, int r0, int r1, int c0, int c1, float fx, float fy, float cx,
+                                    float cy, float* cloud, void* stream) {
+  SAM6D_REQUIRE(depth && cloud, "depth_to_cloud: null pointer");
+  SAM6D_REQUIRE(H > 0 && W > 0 && 0 <= r0 && r0 <= r1 && r1 <= H && 0 <= c0 && c0 <= c1 && c1 <= W,
+                "depth_to_cloud: bbox [%d,%d)x[%d,%d) outside the %dx%d depth map", r0, r1, c0, c1, H, W);
+  const long total = (long)(r1 - r0) * (c1 - c0);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(depth_to_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, depth, W,
+                     r0, c0, r1 - r0, c1 - c0, fx, fy, cx, cy, cloud);
+  SAM6D_LAUNCH_CHECK("depth_to_cloud");
 }

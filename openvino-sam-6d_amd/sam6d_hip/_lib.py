@@ -57,6 +57,12 @@ SIGNATURES = {
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "sam6d_radius_normalize": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_masked_patch_normalize": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
+    "sam6d_depth_to_cloud": [c_p] + [c_i] * 6 + [c_f] * 4 + [c_p, c_p],
+    "sam6d_detections_small_keep": [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p],
+    "sam6d_mask_to_indices": [c_p, c_i, c_p, c_p, c_p],
+    "sam6d_take_rows": [c_p, c_p, c_l, c_i, c_l, c_p, c_p],
+    "sam6d_nms_workspace_bytes": [c_i],
+    "sam6d_nms": [c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
 }
 
@@ -80,7 +86,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
-        fn.restype = c_i
+        fn.restype = ctypes.c_size_t if name.endswith("_bytes") else c_i
     mode = os.environ.get("SAM6D_MATMUL_MODE")  # 0 = exact fp32 MFMA, 1 = fp16x3 split (library default)
     if mode is not None:
         if lib.sam6d_set_matmul_mode(int(mode)) != 0:

@@ -109,3 +109,67 @@ def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thres
     _lib.call("sam6d_masked_patch_normalize", _p(f), _p(m), N, P, D, H, W, int(patch_size), float(validpatch_thresh), _p(out),
               _s())
     return out
+
+
+# ------------------------------------------------------------------ Detections bookkeeping (ISM/model/utils.py:84-196)
+def small_detection_keep(boxes, masks, min_box_size, min_mask_size):
+    """ISM/model/utils.py:96-102: bool (N,) -- box area and mask area (as fractions of the image) above the thresholds."""
+    from .ops import _chk
+    boxes = boxes.contiguous()
+    masks = masks.to(torch.float32).contiguous()
+    _chk(boxes, "boxes", torch.int64, 2)
+    _chk(masks, "masks", torch.float32, 3)
+    N, H, W = masks.shape
+    keep = _empty((N,), masks, torch.uint8)
+    _lib.call("sam6d_detections_small_keep", _p(boxes), _p(masks), N, H, W, float(min_box_size ** 2), float(min_mask_size),
+              _p(keep), _s())
+    return keep.bool()
+
+
+def mask_to_indices(keep):
+    """nonzero(keep) as int64 indices (one host read-back of the count, like boolean-mask indexing in torch)."""
+    k8 = keep.to(torch.uint8).contiguous()
+    N = k8.shape[0]
+    idx = _empty((max(N, 1),), k8, torch.int64)
+    cnt = _empty((1,), k8, torch.int32)
+    _lib.call("sam6d_mask_to_indices", _p(k8), N, _p(idx), _p(cnt), _s())
+    return idx[: int(cnt.item())]
+
+
+def take_rows(src, idx):
+    """src[idx] for an int64 index vector or a bool mask, any dtype (ISM/model/utils.py:105,119,126,190)."""
+    if not src.is_cuda:
+        raise RuntimeError("take_rows: src must be a HIP device tensor (no CPU path)")
+    if idx.dtype == torch.bool or idx.dtype == torch.uint8:
+        idx = mask_to_indices(idx)
+    idx = idx.to(torch.int64).contiguous()
+    src = src.contiguous()
+    M = idx.shape[0]
+    out = torch.empty((M,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src.element_size()
+    for d in src.shape[1:]:
+        row_bytes *= d
+    if M and row_bytes:
+        _lib.call("sam6d_take_rows", _p(src), _p(idx), src.shape[0], M, row_bytes, _p(out), _s())
+    return out
+
+
+def nms(boxes, scores, iou_threshold, object_ids=None):
+    """torchvision.ops.nms as ISM/model/utils.py:107-126 calls it; with object_ids the per-id variant (ids ascending,
+    survivors of each id in descending score order).  Returns int64 indices."""
+    from .ops import _chk
+    boxes = boxes.to(torch.float32).contiguous()
+    scores = scores.to(torch.float32).contiguous()
+    _chk(boxes, "boxes", torch.float32, 2)
+    _chk(scores, "scores", torch.float32, 1)
+    N = boxes.shape[0]
+    grp = None
+    if object_ids is not None:
+        grp = object_ids.to(torch.int64).contiguous()
+        _chk(grp, "object_ids", torch.int64, 1)
+    keep = _empty((max(N, 1),), boxes, torch.int64)
+    cnt = _empty((1,), boxes, torch.int32)
+    nbytes = int(_lib.load().sam6d_nms_workspace_bytes(N))
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=boxes.device)
+    _lib.call("sam6d_nms", _p(boxes), _p(scores), _p(grp), N, float(iou_threshold), _p(keep), _p(cnt), _p(ws), nbytes, _s())
+    return keep[: int(cnt.item())]

@@ -574,6 +574,19 @@ def radius_normalize(pts, dense_po):
     return pm, po, radius
 
 
+def depth_to_cloud(depth, K, bbox=None):
+    """get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) on a device depth map (H,W) f32 -> (h,w,3)."""
+    from .ops import _chk
+    depth = depth.contiguous()
+    _chk(depth, "depth", torch.float32, 2)
+    H, W = depth.shape
+    r0, r1, c0, c1 = (0, H, 0, W) if bbox is None else [int(v) for v in bbox]
+    out = _empty((r1 - r0, c1 - c0, 3), depth)
+    _lib.call("sam6d_depth_to_cloud", _p(depth), H, W, r0, r1, c0, c1, float(K[0][0]), float(K[1][1]), float(K[0][2]),
+              float(K[1][2]), _p(out), _s())
+    return out
+
+
 def _cat0(a, b):
     """stack two (B,N,K) tensors along the batch -- a device copy, no arithmetic"""
     a = a.contiguous()

@@ -123,6 +123,28 @@ class RandPatch:
 
 
 # ------------------------------------------------------------------------------------------------- fixtures
+def fx_depth_cloud(ext, mods):
+    """get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) run from the reference itself (empty
+    stub modules for the absent imageio / cv2, which this function does not touch).  K is handed over as float32 so that the
+    result does not depend on the numpy major version (1.26 value-based casting == 2.x with a float32 scalar)."""
+    for name in ("imageio", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    du = importlib.import_module("data_utils")
+    g = np.random.default_rng(5)
+    depth = (g.random((120, 160)) * 1.5 + 0.3).astype(np.float32)
+    depth[g.random((120, 160)) < 0.1] = 0
+    K = np.array([[572.4114, 0, 325.2611], [0, 573.57043, 242.04899], [0, 0, 1]], np.float32)
+    full = du.get_point_cloud_from_depth(depth, K)
+    crop = du.get_point_cloud_from_depth(depth, K, [10, 90, 33, 150])
+    assert full.dtype == np.float32 and crop.dtype == np.float32
+    o_full = O.depth_to_cloud(depth, K)
+    o_crop = O.depth_to_cloud(depth, K, [10, 90, 33, 150])
+    assert np.array_equal(o_full, full) and np.array_equal(o_crop, crop), "oracle depth_to_cloud differs from the reference"
+    save("depth_cloud", depth=depth, K=K, bbox=np.array([10, 90, 33, 150], np.int32), full_sha=sha(torch.from_numpy(full.copy())),
+         crop=crop)
+
+
 def fx_pointops(ext, mods):
     g = gen(11)
     xyz = torch.rand(2, 2048, 3, generator=g) - 0.5
@@ -549,7 +571,7 @@ def fx_ism():
 
 
 ALL = ["pointops", "pairwise", "geo", "transformer", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
-       "fine_rt", "procrustes", "pem_e2e", "ism"]
+       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "ism"]
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

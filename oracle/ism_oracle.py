@@ -5,6 +5,7 @@ Functional torch-CPU restatement; each function cites the reference file:line it
 leg may import this module.  Pinned by tests/test_oracle_golden.py against vectors captured from the reference's
 own model/loss.py, model/detector.py, utils/bbox_utils.py and utils/trimesh_utils.py (oracle/gen_golden.py).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -119,3 +120,49 @@ def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thres
     keep = torch.nn.AvgPool2d(kernel_size=patch_size, stride=patch_size)(masks).flatten(-2) > validpatch_thresh
     keep = keep.unsqueeze(-1).repeat(1, 1, patch_features.shape[-1])
     return F.normalize(patch_features * keep, dim=-1)
+
+
+# --------------------------------------------------------------- Detections bookkeeping (ISM/model/utils.py)
+def small_detection_keep(boxes, masks, min_box_size, min_mask_size):
+    """ISM/model/utils.py:96-102; torchvision's box_area is (x2 - x1) * (y2 - y1)."""
+    img_area = masks.shape[1] * masks.shape[2]
+    box_areas = ((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])) / img_area
+    mask_areas = masks.sum(dim=(1, 2)) / img_area
+    return torch.logical_and(box_areas > min_box_size ** 2, mask_areas > min_mask_size)
+
+
+def nms(boxes, scores, thresh):
+    """torchvision.ops.nms, restated from torchvision's published CPU kernel (torchvision 0.15.1 / 0.20.x pinned by the
+    reference's environment files; the package is NOT installed here -> PARITY UNPINNED for this function): stable
+    descending sort by score; walk the order, keep a box unless suppressed, suppress every later box whose
+    IoU = inter / (area_i + area_j - inter) exceeds thresh.  Returns the kept indices in descending-score order."""
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    s = scores.detach().cpu().numpy().astype(np.float32)
+    n = b.shape[0]
+    order = np.argsort(-s, kind="stable")
+    areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    dead = np.zeros(n, bool)
+    keep = []
+    for a in range(n):
+        i = order[a]
+        if dead[i]:
+            continue
+        keep.append(int(i))
+        rest = order[a + 1:]
+        w = np.maximum(np.float32(0), np.minimum(b[i, 2], b[rest, 2]) - np.maximum(b[i, 0], b[rest, 0]))
+        h = np.maximum(np.float32(0), np.minimum(b[i, 3], b[rest, 3]) - np.maximum(b[i, 1], b[rest, 1]))
+        inter = (w * h).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[rest] - inter)
+        dead[rest[ovr > np.float32(thresh)]] = True
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+def nms_per_object_id(boxes, scores, object_ids, thresh):
+    """ISM/model/utils.py:107-117: NMS inside each object id, ids in torch.unique (ascending) order."""
+    all_idx = torch.arange(len(object_ids))
+    out = []
+    for oid in torch.unique(object_ids):
+        sel = object_ids == oid
+        out.append(all_idx[sel][nms(boxes[sel].float(), scores[sel].float(), thresh)])
+    return torch.cat(out) if out else torch.zeros(0, dtype=torch.int64)

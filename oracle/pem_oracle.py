@@ -371,6 +371,23 @@ def radius_normalize(pts, dense_po):
     return pts / (radius.reshape(-1, 1, 1) + 1e-6), dense_po / (radius.reshape(-1, 1, 1) + 1e-6), radius
 
 
+def depth_to_cloud(depth, K, bbox=None):
+    """PEM/utils/data_utils.py:92-110 (get_point_cloud_from_depth), fp32 throughout as under the numpy 1.x value-based
+    casting the reference environment pins (K's float64 scalars do not promote the float32 maps)."""
+    import numpy as np
+    fx, fy, cx, cy = [np.float32(v) for v in (K[0][0], K[1][1], K[0][2], K[1][2])]
+    H, W = depth.shape
+    xmap = np.tile(np.arange(W, dtype=np.float32)[None, :], (H, 1))
+    ymap = np.tile(np.arange(H, dtype=np.float32)[:, None], (1, W))
+    if bbox is not None:
+        rmin, rmax, cmin, cmax = bbox
+        depth, xmap, ymap = depth[rmin:rmax, cmin:cmax], xmap[rmin:rmax, cmin:cmax], ymap[rmin:rmax, cmin:cmax]
+    pt2 = depth.astype(np.float32)
+    pt0 = (xmap - cx) * pt2 / fx
+    pt1 = (ymap - cy) * pt2 / fy
+    return np.stack([pt0, pt1, pt2]).transpose((1, 2, 0))
+
+
 # -------------------------------------------------------------------------------- modules (a14)
 def coarse_point_matching(p1, f1, g1, p2, f2, g2, radius, model, sd, rand, cfg=DEFAULT_CFG, faithful=False,
                           return_aux=False, p="coarse_point_matching"):

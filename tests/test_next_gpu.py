@@ -75,3 +75,118 @@ def test_vit_encoder_forward_uses_hip_radius(dev):
     fe = importlib.import_module("feature_extraction")
     src = open(fe.__file__).read()
     assert "_pem.radius_normalize" in src and "torch.norm(dense_po" not in src
+
+
+# ---------------------------------------------------------------------------- depth back-projection (row f2)
+def test_depth_to_cloud_golden_bit_exact(dev):
+    from tests._util import golden
+    from sam6d_hip import pem
+    g = golden("depth_cloud")
+    depth = torch.from_numpy(g["depth"]).to(dev)
+    crop = pem.depth_to_cloud(depth, g["K"], [int(v) for v in g["bbox"]]).cpu().numpy()
+    assert np.array_equal(crop, g["crop"])
+    import hashlib
+    full = pem.depth_to_cloud(depth, g["K"]).cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["full_sha"])
+    with pytest.raises(RuntimeError):
+        pem.depth_to_cloud(depth, g["K"], [0, 121, 0, 10])  # bbox outside the map
+
+
+# ---------------------------------------------------------------------------- Detections bookkeeping (row f3)
+def _rand_boxes(g, n, size=480):
+    xy = torch.rand(n, 2, generator=g) * (size - 80)
+    wh = torch.rand(n, 2, generator=g) * 70 + 4
+    return torch.cat([xy, xy + wh], 1).round()
+
+
+@pytest.mark.parametrize("N,thr", [(0, 0.5), (1, 0.5), (37, 0.25), (300, 0.5), (1000, 0.25), (4500, 0.7)])
+def test_nms_matches_oracle(dev, N, thr):
+    from oracle import ism_oracle as O
+    from sam6d_hip import ism
+    g = torch.Generator().manual_seed(N + 11)
+    boxes = _rand_boxes(g, N)
+    if N > 20:  # clusters of near-duplicates around the first boxes + exact score ties
+        boxes[N // 2:] = boxes[: N - N // 2] + torch.randint(-3, 4, (N - N // 2, 4), generator=g).float()
+    scores = (torch.rand(N, generator=g) * 50).round() / 50  # many ties -> the stable order matters
+    want = O.nms(boxes, scores, thr)
+    got = ism.nms(boxes.to(dev), scores.to(dev), thr).cpu()
+    assert got.dtype == torch.int64 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("N,n_obj", [(1, 1), (64, 3), (500, 7)])
+def test_nms_per_object_id_matches_oracle(dev, N, n_obj):
+    from oracle import ism_oracle as O
+    from sam6d_hip import ism
+    g = torch.Generator().manual_seed(N * 3 + n_obj)
+    boxes = _rand_boxes(g, N, 200)
+    scores = torch.rand(N, generator=g)
+    oid = torch.randint(0, n_obj, (N,), generator=g) * 5 - 3  # non-contiguous ids, one negative
+    want = O.nms_per_object_id(boxes, scores, oid, 0.5)
+    got = ism.nms(boxes.to(dev), scores.to(dev), 0.5, object_ids=oid.to(dev)).cpu()
+    assert torch.equal(got, want)
+
+
+def test_detections_class_matches_reference_semantics(dev):
+    """The drop-in Detections (ISM/model/utils.py:84-196): area filter -> attributes -> per-id NMS -> filter, against the
+    oracle's restatement of every step."""
+    import importlib
+    import sys
+    import os
+    from oracle import ism_oracle as O
+    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(PKG, "ism"))
+    U = importlib.import_module("model.utils")
+
+    class Cfg:
+        min_box_size = 0.05
+        min_mask_size = 3e-4
+
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 120, 96, 128
+    boxes = _rand_boxes(g, N, 128).clamp(0, 95).long()
+    boxes[:10, 2:] = boxes[:10, :2] + 2  # tiny boxes
+    masks = torch.zeros(N, H, W)
+    for i in range(N):
+        x0, y0, x1, y1 = boxes[i].tolist()
+        masks[i, y0:y1, x0:x1] = (torch.rand(max(y1 - y0, 0), max(x1 - x0, 0), generator=g) > 0.4).float()
+    masks[10:14] = 0  # empty masks
+    det = U.Detections({"masks": masks.to(dev), "boxes": boxes.float().to(dev)})
+    assert det.boxes.dtype == torch.int64
+    keep = O.small_detection_keep(boxes, masks, Cfg.min_box_size, Cfg.min_mask_size)
+    assert 0 < int(keep.sum()) < N
+    det.remove_very_small_detections(Cfg)
+    assert torch.equal(det.boxes.cpu(), boxes[keep]) and torch.equal(det.masks.cpu(), masks[keep])
+    b2, m2 = boxes[keep], masks[keep]
+    n2 = len(b2)
+    scores = torch.rand(n2, generator=g)
+    oid = torch.randint(0, 4, (n2,), generator=g)
+    det.add_attribute("scores", scores.to(dev))
+    det.add_attribute("object_ids", oid.to(dev))
+    det.check_size()
+    kidx = O.nms_per_object_id(b2.float(), scores, oid, 0.25)
+    det.apply_nms_per_object_id(nms_thresh=0.25)
+    assert len(det) == len(kidx) < n2
+    assert torch.equal(det.scores.cpu(), scores[kidx]) and torch.equal(det.object_ids.cpu(), oid[kidx])
+    assert torch.equal(det.boxes.cpu(), b2[kidx]) and torch.equal(det.masks.cpu(), m2[kidx])
+    c = det.clone()
+    sel = torch.tensor([3, 0, -1, 3])
+    c.filter(sel.to(dev))
+    assert torch.equal(c.scores.cpu(), scores[kidx][sel]) and torch.equal(c.masks.cpu(), m2[kidx][sel])
+    assert len(det) == len(kidx)  # the clone was filtered, not the original
+    c.apply_nms(0.5)
+    assert torch.equal(c.scores.cpu(), scores[kidx][sel][O.nms(b2[kidx][sel].float(), scores[kidx][sel], 0.5)])
+    det.to_numpy()
+    assert isinstance(det.masks, np.ndarray)
+
+
+def test_take_rows_dtypes(dev):
+    from sam6d_hip import ism
+    g = torch.Generator().manual_seed(1)
+    idx = torch.tensor([5, 0, 0, 7, -2])
+    for t in (torch.rand(8, 3, 5, generator=g), torch.randint(0, 9, (8,), generator=g), torch.rand(8, 4, generator=g) > 0.5,
+              torch.randint(0, 255, (8, 7), generator=g).to(torch.uint8), torch.rand(8, 16, generator=g).double()):
+        assert torch.equal(ism.take_rows(t.to(dev), idx.to(dev)).cpu(), t[idx])
+        m = torch.tensor([1, 0, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
+        assert torch.equal(ism.take_rows(t.to(dev), m.to(dev)).cpu(), t[m])
+    assert ism.take_rows(torch.rand(4, 2).to(dev), torch.zeros(0, dtype=torch.int64).to(dev)).shape == (0, 2)

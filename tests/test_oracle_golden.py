@@ -275,3 +275,36 @@ def test_ism_scoring():
     bq[3] = torch.tensor([0, 0, 2, 2])
     xyxy = torch.cat((vu.min(1).values, vu.max(1).values), -1)
     assert IO.compute_iou(xyxy, bq) == 0.0 and float(g["iou_quirk"]) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ next rows
+def test_depth_to_cloud_matches_reference_capture():
+    """get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) captured from the reference (oracle/gen_golden.py)."""
+    g = golden("depth_cloud")
+    full = O.depth_to_cloud(g["depth"], g["K"])
+    assert _sha(torch.from_numpy(np.ascontiguousarray(full))) == str(g["full_sha"])
+    crop = O.depth_to_cloud(g["depth"], g["K"], [int(v) for v in g["bbox"]])
+    assert np.array_equal(crop, g["crop"])
+
+
+def test_nms_oracle_known_answers():
+    """torchvision.ops.nms restated (PARITY UNPINNED: torchvision is not installed); known answers worked by hand."""
+    b = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.0], [0, 0, 10, 5]])
+    s = torch.tensor([0.9, 0.8, 0.7, 0.9, 0.95])
+    # box 4 (score .95) overlaps 0 and 3 with IoU exactly 0.5 -> NOT suppressed at thresh 0.5 (strict >); 0 kills 3 (tie, stable) and 1
+    assert IO.nms(b, s, 0.5).tolist() == [4, 0, 2]
+    assert IO.nms(b, s, 0.49).tolist() == [4, 1, 2]
+    assert IO.nms_per_object_id(b, s, torch.tensor([1, 0, 1, 1, 0]), 0.5).tolist() == [4, 1, 0, 2]
+    assert IO.nms(b[:0], s[:0], 0.5).tolist() == []
+
+
+def test_small_detection_keep_oracle():
+    boxes = torch.tensor([[0, 0, 10, 10], [0, 0, 3, 3], [5, 5, 40, 40]])
+    masks = torch.zeros(3, 50, 50)
+    masks[0, :10, :10] = 1
+    masks[1, :3, :3] = 1
+    masks[2, 5:8, 5:8] = 1
+    keep = IO.small_detection_keep(boxes, masks, 0.05, 3e-4)  # 0.05**2 = 6.25 px of 2500 -> box area > 6.25; mask > 0.75 px
+    assert keep.tolist() == [True, True, True]
+    keep = IO.small_detection_keep(boxes, masks, 0.1, 5e-3)  # box area > 25 px, mask area > 12.5 px
+    assert keep.tolist() == [True, False, False]
