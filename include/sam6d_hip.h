@@ -104,6 +104,15 @@ int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div_term, cons
 int sam6d_split_f16(const float* x, long n, float scale, void* hi, void* lo, void* stream);
 int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
                        const float* ba, int hidden, const int* flag, float* out, void* stream);
+/* Same contract as sam6d_geo_embed_h3 (PEM/model/transformer.py:343-363) with the sinusoid contraction replaced by a
+ * 32-term Chebyshev expansion of proj_d(sinusoid(x)) / proj_a(sinusoid(x)) on [0, xmax] (w_cheb: 2 x 256 rows of
+ * 144 B = 32 hi | 32 lo | 8 pad fp16 halves of coefficient * 1024, built at weight-load time in float64).  Pairs with
+ * an index outside [0, xmax] are collected in list_ws (1 + pairs ints, device) and recomputed with the sinusoid kernel
+ * (div_term, w_packed as for sam6d_geo_embed_h3), so the result is independent of xmax up to the ~1e-7 split-precision
+ * error.  No-op when *flag != 0 (indices beyond the fast-sincos range: follow with sam6d_geo_embed(only_if_large=1)). */
+int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, float xmax, const float* div_term,
+                         const void* w_packed, const float* bd, const float* ba, int hidden, const int* flag, int* list_ws,
+                         float* out, void* stream);
 
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).

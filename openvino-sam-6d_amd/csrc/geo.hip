@@ -211,13 +211,16 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define GH_BROW 80                      // bytes per weight row image: 16 hi halves | 16 lo halves | 16 B pad
 #define GH_BCHUNK (2 * 256 * GH_BROW)   // 40 960 B: one 16-wide K chunk of {proj_d, proj_a}
 #define GH_ABYTES (2 * 4 * GH_P * GH_LD * 2)
-#define GH_LDS_BYTES (GH_ABYTES + 2 * GH_BCHUNK + 4 * GH_P * 4 + 128 * 4)
+#define GH_LDS_BYTES (GH_ABYTES + 2 * GH_BCHUNK + 4 * GH_P * 4 + 128 * 4 + GH_P * 4)
 
 __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
                                                            const unsigned char* __restrict__ Wp, const float* __restrict__ bd,
                                                            const float* __restrict__ ba, float* __restrict__ out, long total,
-                                                           const int* __restrict__ maxflag) {
+                                                           const int* __restrict__ maxflag, const int* __restrict__ list) {
   if (*maxflag != 0) return;  // an index beyond the fast sincos range: the exact kernel launched next handles the call
+  // list mode (fix-up pass behind geo_cheb_kernel): list[0] = number of listed pairs, list[1..] = their flat pair ids
+  if (list) total = list[0];
+  if ((long)blockIdx.x * GH_P >= total) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][24]
   _Float16* Al = Ah + 4 * GH_P * GH_LD;
@@ -237,12 +240,16 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
                                        (void __attribute__((address_space(3)))*)(dst + i * 1024), 16, 0, 0);
   };
   dma(0);
+  int* pid = reinterpret_cast<int*>(om + 128);  // [64] flat pair id of each slot (list mode)
   if (t < GH_P) {
-    const float4 v = idx4[min(p0 + t, total - 1)];
+    const long slot = min(p0 + t, total - 1);
+    const long e = list ? (long)list[1 + slot] : slot;
+    const float4 v = idx4[e];
     xs[0 * GH_P + t] = v.x;
     xs[1 * GH_P + t] = v.y;
     xs[2 * GH_P + t] = v.z;
     xs[3 * GH_P + t] = v.w;
+    pid[t] = (int)e;
   }
   if (t >= 256 && t < 384) om[t - 256] = div_term[t - 256];
   f32x16 acc[4][2];
@@ -303,8 +310,9 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
     const float vbd = bd[col], vba = ba[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long e = p0 + ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-      if (e < total) {
+      const int sl = ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (p0 + sl < total) {
+        const long e = list ? (long)pid[sl] : p0 + sl;
         const float d = acc[0][j][r] * unscale + vbd;
         const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) * unscale + vba;
         out[e * 256 + col] = d + a;
@@ -332,12 +340,7 @@ extern "C" int sam6d_split_f16(const float* x, long n, float scale, void* hi, vo
   SAM6D_LAUNCH_CHECK("split_f16");
 }
 
-extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
-                                  const float* ba, int hidden, const int* flag, float* out, void* stream) {
-  SAM6D_REQUIRE(idx_ws && div_term && w_packed && bd && ba && out && flag, "geo_embed_h3: null pointer");
-  SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed_h3: hidden_dim must be 256");
-  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed) & 15) == 0, "geo_embed_h3: idx_ws/weights must be 16-byte aligned");
-  if (pairs == 0) return 0;
+static int h3_reserve_lds() {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_embed_h3_kernel),
@@ -348,10 +351,189 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
     }
     attr_set = true;
   }
+  return 0;
+}
+
+extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, const void* w_packed, const float* bd,
+                                  const float* ba, int hidden, const int* flag, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && w_packed && bd && ba && out && flag, "geo_embed_h3: null pointer");
+  SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed_h3: hidden_dim must be 256");
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed) & 15) == 0, "geo_embed_h3: idx_ws/weights must be 16-byte aligned");
+  if (pairs == 0) return 0;
+  if (int rc = h3_reserve_lds()) return rc;
   hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES,
                      (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), div_term,
-                     reinterpret_cast<const unsigned char*>(w_packed), bd, ba, out, pairs, flag);
+                     reinterpret_cast<const unsigned char*>(w_packed), bd, ba, out, pairs, flag, (const int*)nullptr);
   SAM6D_LAUNCH_CHECK("geo_embed_h3");
+}
+
+
+
+// ------------------------------------------------------------------------------------- 3c. embedding, Chebyshev basis
+// proj_d(sinusoid(x)) and proj_a(sinusoid(x)) are, per output column, smooth 1-D functions of the scalar index x
+// (a sum of 128 sin/cos pairs with frequencies <= 1 rad per unit).  On [0, xmax] each is reproduced to ~1e-11 by its
+// degree-31 Chebyshev interpolant (weight-load time, float64), so the 256-deep sinusoid contraction collapses to a
+// 32-deep one against T_0..T_31(2x/xmax - 1):  8x fewer MFMAs and no sin/cos at all.  The basis is generated per scalar
+// by the three-term recurrence in fp64 (exact to fp32), split into fp16 hi/lo and contracted on v_mfma_f32_32x32x16_f16
+// with the same 3-product split arithmetic as above.  With the contraction this cheap the kernel is bound by the HBM
+// write of E (1 KiB per pair).
+// Pairs with an index outside [0, xmax] (the bg token at (100,100,100): d_idx ~ 870; 2n-1 of n^2 pairs) are appended to
+// a list and recomputed by geo_embed_h3_kernel in list mode.
+// Persistent workgroups (one per CU): the two coefficient matrices stay in LDS (72 KiB), the generated A tile is
+// double-buffered so that the recurrence for tile i+1 runs under the MFMAs / stores of tile i.
+#define GC_K 32
+#define GC_ROW 144                       // bytes per row image: 32 hi halves | 32 lo halves | 16 B pad
+#define GC_WBYTES (2 * 256 * GC_ROW)     // 73 728
+#define GC_ABYTES (4 * GH_P * GC_ROW)    // 36 864 per buffer
+#define GC_LDS_BYTES (GC_WBYTES + 2 * GC_ABYTES)
+__global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict__ idx4, const unsigned char* __restrict__ Wc,
+                                                       const float* __restrict__ bd, const float* __restrict__ ba,
+                                                       float* __restrict__ out, long total, float xmax,
+                                                       const int* __restrict__ maxflag, int* __restrict__ list) {
+  if (*maxflag != 0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned char* Bw = lds_raw;
+  unsigned char* At = lds_raw + GC_WBYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < GC_WBYTES / 16; i += 512)
+    reinterpret_cast<uint4*>(Bw)[i] = reinterpret_cast<const uint4*>(Wc)[i];
+  const long ntiles = (total + GH_P - 1) / GH_P;
+  const int grow = t & 255, ghalf = t >> 8;  // generation: row (group g = grow >> 6, pair slot = grow & 63), which 16 orders
+  const int fr = lane & 31, fk = lane >> 5;
+  const int ph = wave & 1, wn = (wave >> 1) * 64;
+  const double inv = 2.0 / (double)xmax;
+  auto generate = [&](long tile, int buf) {
+    const long e = min(tile * GH_P + (grow & 63), total - 1);
+    const float4 v = idx4[e];
+    const int g = grow >> 6;
+    const float x = g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w;
+    const bool inside = x >= 0.f && x <= xmax;  // false for NaN too
+    if (ghalf == 0) {
+      // one list entry per pair: the lane of group 0 speaks for all four scalars of its pair
+      const bool bad = !(v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f &&
+                         v.w <= xmax);
+      if (g == 0 && bad && tile * GH_P + (grow & 63) < total) list[1 + atomicAdd(list, 1)] = (int)e;
+    }
+    const double u = inside ? (double)x * inv - 1.0 : 0.0;  // listed pairs get a harmless in-range value here
+    const double u2 = u + u;
+    double t0 = 1.0, t1 = u;
+    unsigned char* row = At + buf * GC_ABYTES + grow * GC_ROW;
+    half8 hi[2], lo[2];
+#pragma unroll
+    for (int p = 0; p < GC_K; ++p) {
+      const double tp = p == 0 ? 1.0 : p == 1 ? u : __builtin_fma(u2, t1, -t0);
+      if (p >= 2) {
+        t0 = t1;
+        t1 = tp;
+      }
+      if ((p >> 4) == ghalf) {  // wave-uniform: threads 0..255 keep orders 0..15, threads 256..511 orders 16..31
+        const float f = (float)tp;
+        const _Float16 h = (_Float16)f;
+        hi[(p >> 3) & 1][p & 7] = h;
+        lo[(p >> 3) & 1][p & 7] = (_Float16)(f - (float)h);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<half8*>(row + (ghalf * 16 + q * 8) * 2) = hi[q];
+      *reinterpret_cast<half8*>(row + 64 + (ghalf * 16 + q * 8) * 2) = lo[q];
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < ntiles) generate(tile, 0);
+  __syncthreads();
+  const float unscale = 1.0f / 1024.0f;
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    if (tile + gridDim.x < ntiles) generate(tile + gridDim.x, buf ^ 1);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.f;
+    const unsigned char* Ab = At + buf * GC_ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 bh[2][2], bl[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned char* row = Bw + (size_t)(mt * 256 + wn + 32 * j + fr) * GC_ROW + (ks * 16 + fk * 8) * 2;
+          bh[mt][j] = *reinterpret_cast<const half8*>(row);
+          bl[mt][j] = *reinterpret_cast<const half8*>(row + 64);
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned char* row = Ab + (size_t)(g * GH_P + ph * 32 + fr) * GC_ROW + (ks * 16 + fk * 8) * 2;
+        const half8 ah = *reinterpret_cast<const half8*>(row);
+        const half8 al = *reinterpret_cast<const half8*>(row + 64);
+        const int mt = g ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[mt][j], acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[mt][j], acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[mt][j], acc[g][j], 0, 0, 0);
+        }
+      }
+    }
+    const long p0 = tile * GH_P;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn + j * 32 + fr;
+      const float vbd = bd[col], vba = ba[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long e = p0 + ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (e < total) {
+          const float d = acc[0][j][r] * unscale + vbd;
+          const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) * unscale + vba;
+          out[e * 256 + col] = d + a;
+        }
+      }
+    }
+    __syncthreads();  // every wave is done with buffer `buf`; the next tile's rows (other buffer) are complete
+  }
+}
+
+extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, float xmax, const float* div_term,
+                                    const void* w_packed, const float* bd, const float* ba, int hidden, const int* flag,
+                                    int* list_ws, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && w_cheb && div_term && w_packed && bd && ba && out && flag && list_ws, "geo_embed_cheb: null pointer");
+  SAM6D_REQUIRE(hidden == 256 && pairs >= 0 && pairs < 2147483647L, "geo_embed_cheb: hidden_dim must be 256, pairs < 2^31");
+  SAM6D_REQUIRE(xmax > 0.f, "geo_embed_cheb: xmax must be positive");
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed | (size_t)w_cheb) & 15) == 0,
+                "geo_embed_cheb: idx_ws/weights must be 16-byte aligned");
+  if (pairs == 0) return 0;
+  if (int rc = h3_reserve_lds()) return rc;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_cheb_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS_BYTES);
+    int dev = 0, cu = 0;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cu <= 0) {
+      sam6d_set_error("geo_embed_cheb: cannot reserve %d bytes of LDS / query the device: %s", GC_LDS_BYTES,
+                      hipGetErrorString(e));
+      return e != hipSuccess ? (int)e : SAM6D_EINVAL;
+    }
+    n_cu = cu;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(list_ws, 0, sizeof(int), s);
+  SAM6D_REQUIRE(e == hipSuccess, "geo_embed_cheb: memset failed: %s", hipGetErrorString(e));
+  const long ntiles = (pairs + GH_P - 1) / GH_P;
+  hipLaunchKernelGGL(geo_cheb_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(512), GC_LDS_BYTES, s,
+                     reinterpret_cast<const float4*>(idx_ws), reinterpret_cast<const unsigned char*>(w_cheb), bd, ba, out, pairs,
+                     xmax, flag, list_ws);
+  SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb");
+  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)ntiles), dim3(512), GH_LDS_BYTES, s,
+                     reinterpret_cast<const float4*>(idx_ws), div_term, reinterpret_cast<const unsigned char*>(w_packed), bd, ba,
+                     out, pairs, flag, (const int*)list_ws);
+  SAM6D_LAUNCH_CHECK("geo_embed_cheb(fix-up)");
 }
 
 static int geo_check(int B, int n, int angle_k, int hidden) {

@@ -223,9 +223,10 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     factor_a = 180.0 / (sigma_a * math.pi)
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
     if _lib.load().sam6d_get_matmul_mode() == 1:
+        lst = _empty((B * n * n + 1,), points_bg, torch.int32)  # [count | pair ids outside the Chebyshev range]
         with _Timed("geo_embed_kernel"):
-            _lib.call("sam6d_geo_embed_h3", _p(idx), B * n * n, _p(W.div_term), geo_packed(W).data_ptr(), _p(W.geo_d.b),
-                      _p(W.geo_a.b), C, flag, _p(out), _s())
+            _lib.call("sam6d_geo_embed_cheb", _p(idx), B * n * n, geo_cheb_packed(W).data_ptr(), float(GEO_XMAX), _p(W.div_term),
+                      geo_packed(W).data_ptr(), _p(W.geo_d.b), _p(W.geo_a.b), C, flag, _p(lst), _p(out), _s())
     if _lib.load().sam6d_get_matmul_mode() == 1:
         # indices beyond the fast sincos range (flag set on the device): this launch redoes the call exactly; otherwise
         # it returns immediately
@@ -236,6 +237,44 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
             _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
                       _p(W.geo_a.b), C, flag, 0, _p(out), _s())
     return out
+
+
+GEO_XMAX = 24.0  # Chebyshev range of the embedding indices (d_idx = dist / 0.2, a_idx <= 12); beyond it: the sin/cos kernel
+GEO_CHEB_K = 32
+
+
+def cheb_coefficients(weight, div_term, xmax=GEO_XMAX, K=GEO_CHEB_K):
+    """Chebyshev interpolant (degree K-1, float64) of x -> weight @ sinusoid(x) on [0, xmax], one row per output column:
+    returns c (cols, K) with  weight @ [sin(w0 x), cos(w0 x), sin(w1 x), ...] ~= sum_p c[:, p] T_p(2x/xmax - 1)
+    (SinusoidalPositionalEmbedding: PEM/model/transformer.py:259-285; error ~4e-12 for xmax = 24, K = 32)."""
+    import numpy as np
+    Wm = weight.detach().double().cpu().numpy()  # (cols, 256) over interleaved [sin, cos]
+    om = div_term.detach().double().cpu().numpy()  # (128,)
+    k = np.arange(K)
+    u = np.cos(np.pi * (k + 0.5) / K)
+    ph = ((u + 1.0) * (xmax / 2.0))[:, None] * om[None, :]
+    emb = np.stack([np.sin(ph), np.cos(ph)], -1).reshape(K, -1)  # (K nodes, 256)
+    F = emb @ Wm.T  # (K nodes, cols)
+    T = np.cos(np.outer(np.arange(K), np.arccos(u)))  # T[p, node]
+    c = (2.0 / K) * (T @ F)
+    c[0] *= 0.5
+    return c.T.copy()  # (cols, K)
+
+
+def geo_cheb_packed(W):
+    """Chebyshev coefficient matrices of proj_d / proj_a as geo_cheb_kernel's LDS image: [mat][col][32 hi | 32 lo | 8 pad]
+    fp16 halves of (c * 1024); built once per weight set on the host in float64."""
+    pk = getattr(W, "_geo_cheb", None)
+    if pk is None:
+        import numpy as np
+        c = np.stack([cheb_coefficients(W.geo_d.w, W.div_term), cheb_coefficients(W.geo_a.w, W.div_term)], 0) * 1024.0
+        c32 = c.astype(np.float32)
+        hi = c32.astype(np.float16)
+        lo = (c32 - hi.astype(np.float32)).astype(np.float16)
+        img = np.concatenate([hi, lo, np.zeros((2, C, 8), np.float16)], axis=2)  # (2, 256, 72 halves = 144 B)
+        pk = torch.from_numpy(np.ascontiguousarray(img)).to(W.geo_d.w.device)
+        W._geo_cheb = pk
+    return pk
 
 
 def geo_packed(W):

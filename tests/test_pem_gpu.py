@@ -452,6 +452,34 @@ def test_geo_embedding_large_index_fallback(dev, W, sd):
     assert float((got.cpu() - want).abs().median()) < 0.2
 
 
+@pytest.mark.parametrize("spread", [0.5, 3.0, 12.0])
+def test_geo_embedding_chebyshev_vs_sinusoid_kernels(dev, W, sd, spread):
+    """Default mode: 32-term Chebyshev contraction for indices in [0, 24], the sinusoid kernel (list fix-up) for the rest.
+    spread 0.5: only the bg pairs leave the range; 3.0: a large share of d indices do; 12.0: nearly all of them.  All three
+    must agree with the exact fp32 kernel and the oracle to the split-precision error."""
+    from sam6d_hip import _lib, pem
+    from oracle import pem_oracle as O
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("Chebyshev path is the default (fp16x3) mode")
+    gen = torch.Generator().manual_seed(int(spread * 10))
+    B, n = 3, 197
+    pts = (torch.rand(B, n, 3, generator=gen) - 0.5) * 2 * spread + torch.tensor([0.3, -0.2, 4.0])
+    pts[:, 0] = 100.0  # bg token
+    pts[1, 5] = pts[1, 6]  # duplicate point: d = 0, degenerate angles
+    got = pem.geo_embedding(pts.to(dev), W).cpu()
+    try:
+        _lib.call("sam6d_set_matmul_mode", 0)
+        exact = pem.geo_embedding(pts.to(dev), W).cpu()
+    finally:
+        _lib.call("sam6d_set_matmul_mode", 1)
+    d = float((got - exact).abs().max())
+    scale = float(exact.abs().max())
+    print("\nchebyshev vs exact-fp32 kernel, spread %.1f: max abs diff %.2e (scale %.1f)" % (spread, d, scale))
+    assert d < 3e-6 * max(scale, 1.0)
+    want = O.geo_embedding(pts, sd)
+    _close(got[:, 1:, 1:], want[:, 1:, 1:], 2e-5, "chebyshev geo embedding vs oracle (non-bg pairs)")
+
+
 def test_config5_shape_4096_points(dev, W, sd):
     """BASELINE config 5's geometry (fine_npoint = 4096): the whole path at N = 4096 dense points, B = 1, against the CPU
     oracle (fp32; the config's fp16 attention variant is a later round)."""
