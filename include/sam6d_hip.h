@@ -70,6 +70,10 @@ int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, i
 int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                   float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
                   long sC, long sR, float divisor, int act, void* stream);
+/* sam6d_gemm_nt with a second (inner) batch level and no epilogue: problem (b1, b2) uses A + b1*sA + b2*sA2 etc.
+ * (the per-cloud, per-head q.k^T and P.v products of the attention: PEM/model/transformer.py:137-149, 408-419). */
+int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int K, long lda, long ldw, long ldc, int batch,
+                     long sA, long sW, long sC, int batch2, long sA2, long sW2, long sC2, void* stream);
 
 /* Matrix-core arithmetic of gemm_nt / geo_embed: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
  * 1 = fp16 x3 split (x = hi + lo in fp16, 3 MFMAs, ~1e-6 relative; default).  Both replace the same F.linear call
@@ -107,12 +111,31 @@ int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* div_term, c
 /* Same contract as sam6d_geo_embed_h3 (PEM/model/transformer.py:343-363) with the sinusoid contraction replaced by a
  * 32-term Chebyshev expansion of proj_d(sinusoid(x)) / proj_a(sinusoid(x)) on [0, xmax] (w_cheb: 2 x 256 rows of
  * 144 B = 32 hi | 32 lo | 8 pad fp16 halves of coefficient * 1024, built at weight-load time in float64).  Pairs with
- * an index outside [0, xmax] are collected in list_ws (1 + pairs ints, device) and recomputed with the sinusoid kernel
+ * an index outside [0, xmax] are marked in pos_ws (pairs ints) / collected in list_ws (1 + pairs ints) and computed by the sinusoid kernel
  * (div_term, w_packed as for sam6d_geo_embed_h3), so the result is independent of xmax up to the ~1e-7 split-precision
  * error.  No-op when *flag != 0 (indices beyond the fast-sincos range: follow with sam6d_geo_embed(only_if_large=1)). */
 int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, float xmax, const float* div_term,
-                         const void* w_packed, const float* bd, const float* ba, int hidden, const int* flag, int* list_ws,
-                         float* out, void* stream);
+                         const void* w_packed, const float* bd, const float* ba, int hidden, const int* flag, int* pos_ws,
+                         int* list_ws, float* out, void* stream);
+
+/* Fused RPE self-attention (RPETransformerLayer, PEM/model/transformer.py:366-420, on top of
+ * GeometricStructureEmbedding :343-363) WITHOUT a materialised embedding.  Three entry points:
+ *
+ * sam6d_geo_outliers: after sam6d_geo_indices.  pos_ws[pair] (pairs ints) = -1 when all four indices of the pair lie in
+ *   [0, xmax], else its row in `rows` (pairs x 256 floats capacity; only the listed rows are written): the bias-free
+ *   embedding proj_d(sin(d)) + max_k proj_a(sin(a_k)) of that pair from the sinusoid kernels (w_packed / Wd / Wa, flag as
+ *   for sam6d_geo_embed_h3 / sam6d_geo_embed).  list_ws: 1 + pairs ints of scratch.
+ * sam6d_rpe_scores: P[q][h][0..n) (row stride ldp) = softmax_m((qk[q][h][m] + qp[q][h][:] . E[q][m][:]) / 8) for the Q = B*n
+ *   queries, E rebuilt per key tile from the 32-term Chebyshev basis (wa_cheb = the proj_a half of the sam6d_geo_embed_cheb
+ *   image; qd[q][h][0..32) = D_c^T qp[q][h], D_c = Chebyshev coefficients of proj_d) or read from `rows` for listed pairs.
+ *   qp (Q,4,256) = proj_p folded into the query (see sam6d_attention), qk (Q,4,ldp) = q_h . k_h[m].
+ * sam6d_transpose: dst[b][c][j] = src[b][j][c] (the values as the N x K operand of the P.V GEMM). */
+int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, const float* div_term, const void* w_packed, const float* Wd,
+                       const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows, void* stream);
+int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const float* rows, const void* wa_cheb, float xmax, const float* qp,
+                     const float* qd, const float* qk, float* P, long Q, int n, int ldp, void* stream);
+int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n, int ncol, float* dst, long ld_dst,
+                    long stride_dst, void* stream);
 
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).

@@ -20,22 +20,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // problems; 64x64 when the 128-tile grid would not fill the 256 CUs (the 197-token sparse layers: M = 6 304 / 12 608).
 // The next K tile is fetched into registers while the current one is multiplied (global latency hidden behind 16-32
 // MFMAs per wave).
+// second (inner) batch level: workgroup z = b1 * n2 + b2 addresses  base + b1 * s + b2 * s2   (n2 == 1: plain batch)
+struct Batch2 {
+  int n2;
+  long sA2, sW2, sC2, sR2;
+};
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                       const float* __restrict__ bias, const float* __restrict__ colscale,
                                                       const float* __restrict__ residual, float* __restrict__ C, int M, int N,
                                                       int K, long lda, long ldw, long ldc, long ldr, long sA, long sW, long sC,
-                                                      long sR, float divisor, int act) {
+                                                      long sR, float divisor, int act, Batch2 b2) {
   constexpr int TM = BM / 64, TN = BN / 64;  // MFMA tiles per wave
   constexpr int RA = BM / 64, RB = BN / 64;  // float4 staging loads per thread
   __shared__ float As[BM * GM_LD];
   __shared__ float Bs[BN * GM_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bz = blockIdx.z;
-  A += (size_t)bz * sA;
-  W += (size_t)bz * sW;
-  C += (size_t)bz * sC;
-  if (residual) residual += (size_t)bz * sR;
+  const int bz = blockIdx.z / b2.n2, bi = blockIdx.z % b2.n2;
+  A += (size_t)bz * sA + (size_t)bi * b2.sA2;
+  W += (size_t)bz * sW + (size_t)bi * b2.sW2;
+  C += (size_t)bz * sC + (size_t)bi * b2.sC2;
+  if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
-                                                         long sC, long sR, float divisor, int act, int wide) {
+                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RA = BM / 32, RB = BN / 32;  // float4 staging loads per thread (32 rows x 8 float4 per pass)
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * H_LD];  // also the epilogue's transpose slabs
@@ -178,11 +184,11 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   _Float16* Bh = Al + BM * H_LD;
   _Float16* Bl = Bh + BN * H_LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bz = blockIdx.z;
-  A += (size_t)bz * sA;
-  W += (size_t)bz * sW;
-  C += (size_t)bz * sC;
-  if (residual) residual += (size_t)bz * sR;
+  const int bz = blockIdx.z / b2.n2, bi = blockIdx.z % b2.n2;
+  A += (size_t)bz * sA + (size_t)bi * b2.sA2;
+  W += (size_t)bz * sW + (size_t)bi * b2.sW2;
+  C += (size_t)bz * sC + (size_t)bi * b2.sC2;
+  if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
@@ -363,27 +369,29 @@ extern "C" int sam6d_set_matmul_mode(int mode) {
 }
 extern "C" int sam6d_get_matmul_mode(void) { return g_matmul_mode; }
 
-extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale,
-                             const float* residual, float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr,
-                             int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream) {
+static int gemm_launch(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
+                       float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
+                       long sC, long sR, Batch2 b2, float divisor, int act, void* stream) {
   SAM6D_REQUIRE(A && W && C, "gemm_nt: null pointer");
-  SAM6D_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm_nt: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  SAM6D_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0 && b2.n2 >= 1, "gemm_nt: bad sizes M=%d N=%d K=%d batch=%d x %d", M, N,
+                K, batch, b2.n2);
   SAM6D_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm_nt: leading dimension smaller than the row length");
   SAM6D_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (ReLU)");
-  SAM6D_REQUIRE(batch <= 65535, "gemm_nt: batch must be <= 65535");
+  SAM6D_REQUIRE((long)batch * b2.n2 <= 65535, "gemm_nt: batch (x batch2) must be <= 65535");
   if (M == 0 || N == 0 || batch == 0) return 0;
-  const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * batch;
+  const int nz = batch * b2.n2;
+  const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * nz;
   const bool big = blocks128 >= 1024;  // >= 4 workgroups per CU: big tiles
-  dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64), batch);  // M tiles on x (2^31 limit)
+  dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64), nz);  // M tiles on x (2^31 limit)
   SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
   hipStream_t st = (hipStream_t)stream;
 #define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
-                     sC, sR, divisor, act, ##__VA_ARGS__)
+                     sC, sR, divisor, act, b2, ##__VA_ARGS__)
   if (g_matmul_mode == 1 && K >= 32) {
     // 16-byte epilogue accesses need 4-float alignment of every row start and of the per-column vectors
-    const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (((size_t)C) & 15) == 0 &&
-                      (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (((size_t)residual) & 15) == 0)) &&
+    const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (b2.sC2 & 3) == 0 && (((size_t)C) & 15) == 0 &&
+                      (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (b2.sR2 & 3) == 0 && (((size_t)residual) & 15) == 0)) &&
                       (!bias || (((size_t)bias) & 15) == 0) && (!colscale || (((size_t)colscale) & 15) == 0))
                          ? 1 : 0;
     if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>), wide); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>), wide);
@@ -392,6 +400,19 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
   }
 #undef GEMM_LAUNCH
   SAM6D_LAUNCH_CHECK("gemm_nt");
+}
+
+extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale,
+                             const float* residual, float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr,
+                             int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream) {
+  return gemm_launch(A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
+                     Batch2{1, 0, 0, 0, 0}, divisor, act, stream);
+}
+
+extern "C" int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int K, long lda, long ldw, long ldc,
+                                int batch, long sA, long sW, long sC, int batch2, long sA2, long sW2, long sC2, void* stream) {
+  return gemm_launch(A, W, nullptr, nullptr, nullptr, C, M, N, K, lda, ldw, ldc, 0, batch, sA, sW, sC, 0,
+                     Batch2{batch2, sA2, sW2, sC2, 0}, 1.0f, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

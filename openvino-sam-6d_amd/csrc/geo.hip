@@ -107,15 +107,21 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
                                                            const float* __restrict__ Wd, const float* __restrict__ bd,
                                                            const float* __restrict__ Wa, const float* __restrict__ ba,
                                                            float* __restrict__ out, long total,
-                                                           const int* __restrict__ maxflag, int only_if_large) {
+                                                           const int* __restrict__ maxflag, int only_if_large,
+                                                           const int* __restrict__ list, int compact) {
   if (only_if_large && *maxflag == 0) return;  // fallback launch behind the fp16x3 kernel: nothing to do
+  if (list) total = list[0];                   // list mode: see geo_embed_h3_kernel
+  if ((long)blockIdx.x * GE_P >= total) return;
   __shared__ float As[4 * GE_P * GE_LD];       // 128 rows
   __shared__ float Bs[2 * 256 * GE_LD];        // [mat][col][k]
   __shared__ float xs[4 * GE_P];               // embedding index of each generated row
+  __shared__ int pid[GE_P];                    // output row of each slot
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long p0 = (long)blockIdx.x * GE_P;
   if (t < GE_P) {
-    const long e = min(p0 + t, total - 1);
+    const long slot = min(p0 + t, total - 1);
+    const long e = list ? (long)list[1 + slot] : slot;
+    pid[t] = (int)(compact ? slot : e);
     const float4 v = idx4[e];
     xs[0 * GE_P + t] = v.x;
     xs[1 * GE_P + t] = v.y;
@@ -184,11 +190,12 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wn + j * 32 + fr;
-    const float vbd = bd[col], vba = ba[col];
+    const float vbd = bd ? bd[col] : 0.f, vba = ba ? ba[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long e = p0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-      if (e < total) {
+      const int sl = (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (p0 + sl < total) {
+        const long e = pid[sl];
         const float d = acc[0][j][r] + vbd;
         const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) + vba;
         out[e * 256 + col] = d + a;
@@ -216,7 +223,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restrict__ idx4, const float* __restrict__ div_term,
                                                            const unsigned char* __restrict__ Wp, const float* __restrict__ bd,
                                                            const float* __restrict__ ba, float* __restrict__ out, long total,
-                                                           const int* __restrict__ maxflag, const int* __restrict__ list) {
+                                                           const int* __restrict__ maxflag, const int* __restrict__ list,
+                                                           int compact) {
   if (*maxflag != 0) return;  // an index beyond the fast sincos range: the exact kernel launched next handles the call
   // list mode (fix-up pass behind geo_cheb_kernel): list[0] = number of listed pairs, list[1..] = their flat pair ids
   if (list) total = list[0];
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
     xs[1 * GH_P + t] = v.y;
     xs[2 * GH_P + t] = v.z;
     xs[3 * GH_P + t] = v.w;
-    pid[t] = (int)e;
+    pid[t] = (int)(compact ? slot : e);  // compact: listed pair i -> output row i (no bias: see sam6d_geo_outliers)
   }
   if (t >= 256 && t < 384) om[t - 256] = div_term[t - 256];
   f32x16 acc[4][2];
@@ -277,7 +285,10 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
 #pragma unroll
   for (int u = 0; u < 4; ++u) produce1(0, u);
   for (int kc = 0; kc < 256 / GH_BK; ++kc) {
-    __syncthreads();  // chunk kc-1 consumed; this wave's DMA pieces of chunk kc have landed (vmcnt(0) before the barrier)
+    // global_load_lds completion is counted by vmcnt, but the compiler does not tie the LDS image to it: without this wait
+    // the barrier below is a bare s_barrier and another wave can read a weight row whose DMA is still in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk kc-1 consumed; every wave's DMA pieces of chunk kc have landed
     *reinterpret_cast<half8*>(&Ah[grow * GH_LD + 2 * gf0]) = ahi;
     *reinterpret_cast<half8*>(&Al[grow * GH_LD + 2 * gf0]) = alo;
     __syncthreads();  // A rows and every wave's DMA pieces visible
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wn + j * 32 + fr;
-    const float vbd = bd[col], vba = ba[col];
+    const float vbd = bd ? bd[col] : 0.f, vba = ba ? ba[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int sl = ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -363,11 +374,26 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
   if (int rc = h3_reserve_lds()) return rc;
   hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES,
                      (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), div_term,
-                     reinterpret_cast<const unsigned char*>(w_packed), bd, ba, out, pairs, flag, (const int*)nullptr);
+                     reinterpret_cast<const unsigned char*>(w_packed), bd, ba, out, pairs, flag, (const int*)nullptr, 0);
   SAM6D_LAUNCH_CHECK("geo_embed_h3");
 }
 
 
+
+// pos[pair] = -1 when all four indices of the pair lie in [0, xmax] (Chebyshev range), else its slot in list[1..]; list[0] = count
+__global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax,
+                                                           int* __restrict__ pos, int* __restrict__ list) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const float4 v = idx4[e];
+  const bool ok = v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f && v.w <= xmax;
+  int p = -1;
+  if (!ok) {
+    p = atomicAdd(list, 1);
+    list[1 + p] = (int)e;
+  }
+  pos[e] = p;
+}
 
 // ------------------------------------------------------------------------------------- 3c. embedding, Chebyshev basis
 // proj_d(sinusoid(x)) and proj_a(sinusoid(x)) are, per output column, smooth 1-D functions of the scalar index x
@@ -389,7 +415,7 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
 __global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict__ idx4, const unsigned char* __restrict__ Wc,
                                                        const float* __restrict__ bd, const float* __restrict__ ba,
                                                        float* __restrict__ out, long total, float xmax,
-                                                       const int* __restrict__ maxflag, int* __restrict__ list) {
+                                                       const int* __restrict__ maxflag, const int* __restrict__ pos) {
   if (*maxflag != 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* Bw = lds_raw;
@@ -408,13 +434,7 @@ __global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict_
     const int g = grow >> 6;
     const float x = g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w;
     const bool inside = x >= 0.f && x <= xmax;  // false for NaN too
-    if (ghalf == 0) {
-      // one list entry per pair: the lane of group 0 speaks for all four scalars of its pair
-      const bool bad = !(v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f &&
-                         v.w <= xmax);
-      if (g == 0 && bad && tile * GH_P + (grow & 63) < total) list[1 + atomicAdd(list, 1)] = (int)e;
-    }
-    const double u = inside ? (double)x * inv - 1.0 : 0.0;  // listed pairs get a harmless in-range value here
+    const double u = inside ? (double)x * inv - 1.0 : 0.0;  // listed pairs: a harmless in-range value, row never stored
     const double u2 = u + u;
     double t0 = 1.0, t1 = u;
     unsigned char* row = At + buf * GC_ABYTES + grow * GC_ROW;
@@ -480,6 +500,13 @@ __global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict_
       }
     }
     const long p0 = tile * GH_P;
+    // rows of listed pairs (pos >= 0) belong to the sinusoid kernel: the two kernels never store to the same address
+    unsigned keepmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long e = p0 + ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (e < total && pos[e] < 0) keepmask |= 1u << r;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = wn + j * 32 + fr;
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long e = p0 + ph * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-        if (e < total) {
+        if ((keepmask >> r) & 1u) {
           const float d = acc[0][j][r] * unscale + vbd;
           const float a = fmaxf(fmaxf(acc[1][j][r], acc[2][j][r]), acc[3][j][r]) * unscale + vba;
           out[e * 256 + col] = d + a;
@@ -500,8 +527,9 @@ __global__ __launch_bounds__(512) void geo_cheb_kernel(const float4* __restrict_
 
 extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, float xmax, const float* div_term,
                                     const void* w_packed, const float* bd, const float* ba, int hidden, const int* flag,
-                                    int* list_ws, float* out, void* stream) {
-  SAM6D_REQUIRE(idx_ws && w_cheb && div_term && w_packed && bd && ba && out && flag && list_ws, "geo_embed_cheb: null pointer");
+                                    int* pos_ws, int* list_ws, float* out, void* stream) {
+  SAM6D_REQUIRE(idx_ws && w_cheb && div_term && w_packed && bd && ba && out && flag && list_ws && pos_ws,
+                "geo_embed_cheb: null pointer");
   SAM6D_REQUIRE(hidden == 256 && pairs >= 0 && pairs < 2147483647L, "geo_embed_cheb: hidden_dim must be 256, pairs < 2^31");
   SAM6D_REQUIRE(xmax > 0.f, "geo_embed_cheb: xmax must be positive");
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed | (size_t)w_cheb) & 15) == 0,
@@ -525,15 +553,48 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(list_ws, 0, sizeof(int), s);
   SAM6D_REQUIRE(e == hipSuccess, "geo_embed_cheb: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
+  SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb(classify)");
   const long ntiles = (pairs + GH_P - 1) / GH_P;
   hipLaunchKernelGGL(geo_cheb_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(512), GC_LDS_BYTES, s,
                      reinterpret_cast<const float4*>(idx_ws), reinterpret_cast<const unsigned char*>(w_cheb), bd, ba, out, pairs,
-                     xmax, flag, list_ws);
+                     xmax, flag, (const int*)pos_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb");
   hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)ntiles), dim3(512), GH_LDS_BYTES, s,
                      reinterpret_cast<const float4*>(idx_ws), div_term, reinterpret_cast<const unsigned char*>(w_packed), bd, ba,
-                     out, pairs, flag, (const int*)list_ws);
+                     out, pairs, flag, (const int*)list_ws, 0);
   SAM6D_LAUNCH_CHECK("geo_embed_cheb(fix-up)");
+}
+
+// ------------------------------------------------------------------------------------------ 3d. out-of-range pairs
+// The fused RPE attention (rpe.hip) never materialises E: it rebuilds the in-range part from the Chebyshev basis.  Pairs
+// with an index outside [0, xmax] get their (bias-free) embedding row from the sinusoid kernels once per call, into the
+// compact buffer rows[pos[pair]]; pos[pair] = -1 for in-range pairs.
+extern "C" int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, const float* div_term, const void* w_packed,
+                                  const float* Wd, const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows,
+                                  void* stream) {
+  SAM6D_REQUIRE(idx_ws && div_term && w_packed && Wd && Wa && flag && pos_ws && list_ws && rows, "geo_outliers: null pointer");
+  SAM6D_REQUIRE(pairs >= 0 && pairs < 2147483647L && xmax > 0.f, "geo_outliers: bad sizes");
+  SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_outliers: 16-byte alignment");
+  if (pairs == 0) return 0;
+  if (int rc = h3_reserve_lds()) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(list_ws, 0, sizeof(int), s);
+  SAM6D_REQUIRE(e == hipSuccess, "geo_outliers: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
+  SAM6D_LAUNCH_CHECK_CONT("geo_outliers(classify)");
+  // rows of the listed pairs, bias-free, compact.  The grid covers the worst case (every pair listed); workgroups beyond
+  // the device-side count return at once.  Default: fp16x3 sinusoid kernel; *flag != 0: the exact sincosf kernel.
+  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES, s,
+                     reinterpret_cast<const float4*>(idx_ws), div_term, reinterpret_cast<const unsigned char*>(w_packed),
+                     (const float*)nullptr, (const float*)nullptr, rows, pairs, flag, (const int*)list_ws, 1);
+  SAM6D_LAUNCH_CHECK_CONT("geo_outliers(h3 rows)");
+  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, s,
+                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, (const float*)nullptr, Wa, (const float*)nullptr, rows,
+                     pairs, flag, 1, (const int*)list_ws, 1);
+  SAM6D_LAUNCH_CHECK("geo_outliers(exact rows)");
 }
 
 static int geo_check(int B, int n, int angle_k, int hidden) {
@@ -565,7 +626,8 @@ extern "C" int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embed: idx_ws/weights must be 16-byte aligned");
   if (pairs == 0) return 0;
   hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs, flag, only_if_large);
+                     reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs, flag, only_if_large,
+                     (const int*)nullptr, 0);
   SAM6D_LAUNCH_CHECK("geo_embed");
 }
 

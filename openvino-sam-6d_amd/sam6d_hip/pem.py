@@ -224,9 +224,10 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
     if _lib.load().sam6d_get_matmul_mode() == 1:
         lst = _empty((B * n * n + 1,), points_bg, torch.int32)  # [count | pair ids outside the Chebyshev range]
+        pos = _empty((B * n * n,), points_bg, torch.int32)  # pair -> list slot or -1
         with _Timed("geo_embed_kernel"):
             _lib.call("sam6d_geo_embed_cheb", _p(idx), B * n * n, geo_cheb_packed(W).data_ptr(), float(GEO_XMAX), _p(W.div_term),
-                      geo_packed(W).data_ptr(), _p(W.geo_d.b), _p(W.geo_a.b), C, flag, _p(lst), _p(out), _s())
+                      geo_packed(W).data_ptr(), _p(W.geo_d.b), _p(W.geo_a.b), C, flag, _p(pos), _p(lst), _p(out), _s())
     if _lib.load().sam6d_get_matmul_mode() == 1:
         # indices beyond the fast sincos range (flag set on the device): this launch redoes the call exactly; otherwise
         # it returns immediately
@@ -293,8 +294,82 @@ def geo_packed(W):
     return pk
 
 
+class GeoContext:
+    """What the fused RPE attention needs instead of the (B,n,n,256) embedding tensor: the per-pair embedding indices, the
+    map pair -> stored row for the pairs outside the Chebyshev range, those rows, and the packed coefficient matrices."""
+    __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "dcT", "keep")
+
+    def materialize(self, W):
+        raise NotImplementedError
+
+
+def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
+    """points_bg (B,n,3) with the bg point prepended -> GeoContext (GeometricStructureEmbedding without its output tensor:
+    PEM/model/transformer.py:306-363; the projections are applied inside sam6d_rpe_scores)."""
+    B, n, _ = points_bg.shape
+    pairs = B * n * n
+    knn = _empty((B * n * angle_k + 1,), points_bg, torch.int32)  # + the range flag
+    idx = _empty((B, n, n, 4), points_bg)
+    flag = knn.data_ptr() + 4 * B * n * angle_k
+    _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(180.0 / (sigma_a * math.pi)), angle_k, _p(knn),
+              _p(idx), _s())
+    G = GeoContext()
+    G.B, G.n, G.idx = B, n, idx
+    G.pos = _empty((pairs,), points_bg, torch.int32)
+    lst = _empty((pairs + 1,), points_bg, torch.int32)
+    G.rows = _empty((pairs, C), points_bg)  # capacity for the worst case; only the listed rows are ever touched
+    _lib.call("sam6d_geo_outliers", _p(idx), pairs, float(GEO_XMAX), _p(W.div_term), geo_packed(W).data_ptr(), _p(W.geo_d.w),
+              _p(W.geo_a.w), flag, _p(G.pos), _p(lst), _p(G.rows), _s())
+    img = geo_cheb_packed(W)
+    G.wa_cheb = img.data_ptr() + C * 144  # the proj_a half of the [mat][col][144 B] image
+    G.dcT = geo_dcT(W)
+    G.keep = (knn, lst, img)
+    return G
+
+
+def geo_dcT(W):
+    """(32, 256) fp32: Chebyshev coefficients of proj_d, transposed -- the W operand of qd = qp @ D_c."""
+    d = getattr(W, "_geo_dcT", None)
+    if d is None:
+        c = cheb_coefficients(W.geo_d.w, W.div_term)  # (256, 32) float64
+        d = torch.from_numpy(c.T.copy()).to(device=W.geo_d.w.device, dtype=torch.float32).contiguous()
+        W._geo_dcT = d
+    return d
+
+
+def gemm_b2(A, Wt, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, batch2, sA2, sW2, sC2, a_off=0, w_off=0, c_off=0):
+    _lib.call("sam6d_gemm_nt_b2", _p(A, a_off), _p(Wt, w_off), _p(out, c_off), M, N, K, lda, ldw, ldc, batch, sA, sW, sC, batch2,
+              sA2, sW2, sC2, _s())
+
+
+def rpe_self_layer_fused(x, G, L):
+    """rpe_self_layer without the embedding tensor (rpe.hip): q.k^T and P.v as batched GEMMs, the geometric term rebuilt from
+    the Chebyshev basis inside the score kernel."""
+    Bp, n, _ = x.shape
+    M = Bp * n
+    x2 = x.reshape(M, C)
+    qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
+    qp = _empty((M, H * C), x)
+    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C)
+    qd = _empty((M * H, 32), x)
+    gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32)
+    ldp = (n + 3) // 4 * 4
+    qk = _empty((M, H, ldp), x)
+    gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
+    P = _empty((M, H, ldp), x)
+    _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd), _p(qk), _p(P), M,
+              n, ldp, _s())
+    vT = _empty((Bp, C, ldp), x)
+    _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())
+    hid = _empty((M, C), x)
+    gemm_b2(P, vT, hid, n, 64, n, H * ldp, ldp, C, Bp, n * H * ldp, C * ldp, n * C, H, ldp, 64 * ldp, 64)
+    return _post_attention(hid, x2, L).reshape(Bp, n, C)
+
+
 def rpe_self_layer(x, E, L):
     """x (B',n,256), E (B',n,n,256) -> (B',n,256)   RPETransformerLayer (PEM/model/transformer.py:366-479)."""
+    if isinstance(E, GeoContext):
+        return rpe_self_layer_fused(x, E, L)
     Bp, n, _ = x.shape
     M = Bp * n
     x2 = x.reshape(M, C)
@@ -573,7 +648,11 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     sp, sf, idx = sample_pts_feats(dp, df, n)
     pb = _empty((2 * B, n + 1, 3), dp)
     _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * B, n, _p(pb), _s())
-    E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() == 1
+    if fused and not return_aux:
+        E = geo_context(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    else:
+        E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
     # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip idle;
     # the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs beside it
     # on a second HIP stream and is joined before the fine transformer.

@@ -480,6 +480,55 @@ def test_geo_embedding_chebyshev_vs_sinusoid_kernels(dev, W, sd, spread):
     _close(got[:, 1:, 1:], want[:, 1:, 1:], 2e-5, "chebyshev geo embedding vs oracle (non-bg pairs)")
 
 
+@pytest.mark.parametrize("spread,n", [(0.5, 197), (0.5, 64), (3.0, 197), (12.0, 150)])
+def test_rpe_self_layer_fused_vs_materialised(dev, W, sd, spread, n):
+    """rpe.hip (no embedding tensor: Chebyshev basis + MFMA inside the score kernel, q.k^T / P.v as batched GEMMs) against
+    the same layer on the materialised embedding (attention.hip) and against the oracle layer."""
+    from sam6d_hip import _lib, pem
+    from oracle import pem_oracle as O
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the fused RPE path is the default (fp16x3) mode")
+    gen = torch.Generator().manual_seed(int(spread * 10) + n)
+    B = 3
+    pts = (torch.rand(B, n, 3, generator=gen) - 0.5) * 2 * spread + torch.tensor([0.3, -0.2, 4.0])
+    pts[:, 0] = 100.0
+    x = torch.randn(B, n, 256, generator=gen)
+    L = W.coarse["blocks"][1]["self"]
+    E = pem.geo_embedding(pts.to(dev), W)
+    want = pem.rpe_self_layer(x.to(dev), E, L).cpu()
+    G = pem.geo_context(pts.to(dev), W)
+    got = pem.rpe_self_layer(x.to(dev), G, L).cpu()
+    d = float((got - want).abs().max())
+    print("\nfused vs materialised RPE layer (spread %.1f, n %d): max abs diff %.2e (scale %.1f)" % (spread, n, d, float(want.abs().max())))
+    assert torch.isfinite(got).all() and d < 2e-5
+    ora = O.rpe_transformer_layer(x, x, O.geo_embedding(pts, sd), sd, "coarse_point_matching.transformers.1.layers.0")
+    _close(got, ora, 1e-4, "fused RPE layer vs oracle")
+
+
+def test_pem_match_fused_vs_materialised(dev, W):
+    from sam6d_hip import _lib, pem, synth
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the fused RPE path is the default (fp16x3) mode")
+    inp = synth.config2_inputs(B=3, seed=11)
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    outs = []
+    for fused in (True, False):
+        cfg = dict(pem.DEFAULT_CFG, fused_rpe=fused)
+        outs.append([o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
+                                                    d["model"], W, d["rand"], cfg=cfg)])
+    try:
+        _lib.call("sam6d_set_matmul_mode", 0)
+        exact = [o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
+                                                d["model"], W, d["rand"])]
+    finally:
+        _lib.call("sam6d_set_matmul_mode", 1)
+    for a, b, e, what in zip(outs[0], outs[1], exact, ("R", "t", "score")):
+        print("\n%s: fused-vs-exact %.2e  materialised-vs-exact %.2e" % (what, float((a - e).abs().max()), float((b - e).abs().max())))
+    for a, b, e, what in zip(outs[0], outs[1], exact, ("R", "t", "score")):
+        _close(a, e, 1e-4, "pem_match fused vs exact-fp32 mode: " + what)
+        _close(b, e, 1e-4, "pem_match materialised (Chebyshev) vs exact-fp32 mode: " + what)
+
+
 def test_config5_shape_4096_points(dev, W, sd):
     """BASELINE config 5's geometry (fine_npoint = 4096): the whole path at N = 4096 dense points, B = 1, against the CPU
     oracle (fp32; the config's fp16 attention variant is a later round)."""
