@@ -8,8 +8,8 @@ with inputs resident in HBM when the timed region starts.  N>1: one process per 
 proposals (weak scaling, proposals are independent) and the ranks all-gather the 13 floats/proposal (R, t, score) over
 RCCL inside the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (the geometric-embedding contraction),
-timed with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (rpe_score_kernel: the geometric self-attention
+scores of the six RPE layers, profiles/r01_step4_kernel_stats.csv), timed with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
 algorithm, oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -28,6 +28,10 @@ import torch  # noqa: E402
 
 B_PER_GPU = 32
 GEO_FLOP_PER_CLOUD = 2.0 * 197 * 197 * 4 * 256 * 256  # 20.35 GFLOP: (d + 3 angular rows) x 256x256 per pair
+PROJP_FLOP_PER_CLOUD = 2.0 * 197 * 197 * 256 * 256  # 5.09 GFLOP: proj_p of the embedding, per RPE layer
+# what rpe_score_kernel itself contracts per query token: 3 angular rows x 197 keys x 256 channels x 32 Chebyshev
+# orders, the 4 head dots over 256 channels, the 32-term d part for 4 heads -- fp32-equivalent flops, unpadded
+RPE_FLOP_PER_QUERY = 2.0 * 197 * (3 * 256 * 32 + 4 * 256 + 4 * 32)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 
@@ -112,28 +116,46 @@ def main():
 
     if rank == 0:
         total = world * B * args.steps
-        ev = prof.get("geo_embed_kernel", [])
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        geo_ms = sum(ms) / max(1, len(ms))
-        achieved = (2 * B * GEO_FLOP_PER_CLOUD) / (geo_ms * 1e-3) / 1e12 if ev else None
         split = _lib.load().sam6d_get_matmul_mode() == 1
-        # fp16x3 split mode: every fp32-equivalent product costs 3 fp16 MFMA products, so the bound for ALGORITHMIC
-        # flops is the dense fp16 MFMA peak / 3; exact mode: the fp32 MFMA peak
-        peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
-        traffic = None  # HBM bytes per launch from the PMC pass recorded under profiles/ (not measured live)
+        fused = split and os.environ.get("SAM6D_FUSED_RPE", "1") == "1"
+        kname = "rpe_score_kernel" if fused else "geo_embed_kernel"
+        ev = prof.get(kname, [])
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        k_ms = sum(ms) / max(1, len(ms))
+        traffic = None  # HBM bytes per launch from the PMC passes recorded under profiles/ (not measured live)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj["kernels"]["geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if split and B == B_PER_GPU else None
+            traffic = tj["kernels"][kname if fused else "geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if B == B_PER_GPU else None
         except Exception:
             traffic = None
-        roofline = {"bound": "mfma",
-                    "kernel": ("geo_embed_h3_kernel (v_mfma_f32_32x32x16_f16, fp16x3 split = 3 MFMA products per fp32 product)"
-                               if split else "geo_embed_kernel (v_mfma_f32_32x32x2_f32)") + ", 2B clouds per launch",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
-                    "traffic": traffic, "launch_ms": geo_ms, "launches_timed": len(ms),
-                    "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9,
-                    "executed_mfma_tflops": (3.0 * achieved if split else achieved) if achieved else None,
-                    "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
+        if fused:
+            # one launch = one RPE layer over the 2B stacked clouds (6 launches per step).  `achieved` counts only the
+            # contraction the kernel is formulated as (fp32-equivalent flops; every product costs 3 fp16 MFMA products, so the
+            # bound is the dense fp16 MFMA peak / 3).  The reference computes the same scores with proj_p on a materialised
+            # embedding: 5.09 GFLOP per cloud and layer plus a sixth of the 20.35 GFLOP embedding -- reported beside it.
+            flop = 2 * B * 197 * RPE_FLOP_PER_QUERY
+            achieved = flop / (k_ms * 1e-3) / 1e12 if ev else None
+            peak = PEAK_FP16_MFMA_TFLOPS / 3.0
+            ref_flop = 2 * B * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
+            roofline = {"bound": "mfma",
+                        "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16x3 split = 3 MFMA products per fp32 product), "
+                                  "one RPE layer over 2B clouds per launch, 6 launches per step",
+                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+                        "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
+                        "algorithmic_gflop_per_launch": flop / 1e9,
+                        "executed_mfma_tflops": (3.0 * achieved * (208.0 / 197.0)) if achieved else None,
+                        "reference_formulation_gflop_per_launch": ref_flop / 1e9,
+                        "reference_formulation_tflops": (ref_flop / (k_ms * 1e-3) / 1e12) if ev else None,
+                        "fp16_mfma_peak": PEAK_FP16_MFMA_TFLOPS}
+        else:
+            achieved = (2 * B * GEO_FLOP_PER_CLOUD) / (k_ms * 1e-3) / 1e12 if ev else None
+            peak = PEAK_FP16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+            roofline = {"bound": "mfma",
+                        "kernel": ("geo_cheb_kernel + geo_embed_h3_kernel" if split else "geo_embed_kernel (v_mfma_f32_32x32x2_f32)")
+                                  + ", 2B clouds per launch",
+                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+                        "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
+                        "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
         res = {
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,7 +164,8 @@ def main():
             "config": {"workload": "PEM batch=%d proposals/GPU, 2048 scene + 2048 model pts, 1024 CAD pts, random-init weights "
                                    "(SURVEY 8d config 2)" % B, "proposals_per_gpu": B, "parallelism": "proposal-sharded x%d, "
                                    "RCCL all-gather of 13 floats/proposal" % world,
-                       "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA"},
+                       "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA",
+                       "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding"},
             "roofline": roofline,
         }
         if args.cpu_proposals > 0 and world == 1:

@@ -357,8 +357,9 @@ def rpe_self_layer_fused(x, G, L):
     qk = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
     P = _empty((M, H, ldp), x)
-    _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd), _p(qk), _p(P), M,
-              n, ldp, _s())
+    with _Timed("rpe_score_kernel"):
+        _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd), _p(qk), _p(P),
+                  M, n, ldp, _s())
     vT = _empty((Bp, C, ldp), x)
     _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())
     hid = _empty((M, C), x)
