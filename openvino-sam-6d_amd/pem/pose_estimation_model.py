@@ -6,8 +6,10 @@ import torch.nn as nn
 from feature_extraction import ViTEncoder
 from coarse_point_matching import CoarsePointMatching
 from fine_point_matching import FinePointMatching
-from transformer import GeometricStructureEmbedding
+from transformer import GeometricStructureEmbedding, _sig
 from model_utils import sample_pts_feats
+from sam6d_hip import pem as _pem
+from coarse_point_matching import _cfg_dict
 
 
 class Net(nn.Module):
@@ -26,8 +28,36 @@ class Net(nn.Module):
         dense_pm, dense_fm, dense_po, dense_fo, radius = self.feature_extraction(pts, rgb, rgb_choose, dense_po, dense_fo)
         return self.match(dense_pm, dense_fm, dense_po, dense_fo, radius, model)
 
+    # fused = True: the whole seam runs as one libsam6d_hip pipeline (pem.pem_match: scene / template clouds stacked, RPE
+    # attention without the (B,197,197,256) embedding tensors).  False: module by module through the reference's own call
+    # graph below (geo embeddings materialised and handed from module to module), same results to ~1e-6.
+    fused = True
+
+    def _whole_weights(self):
+        sig = _sig(self)
+        if getattr(self, "_pack_sig", None) != sig:
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith("feature_extraction.")}
+            dev = self.coarse_point_matching.in_proj.weight.device
+            if dev.type != "cuda":
+                raise RuntimeError("Net: parameters must live on a HIP device (model.to('cuda')); there is no CPU path")
+            object.__setattr__(self, "_pack", _pem.PemWeights(sd, dev, nblock=self.coarse_point_matching.nblock))
+            object.__setattr__(self, "_pack_sig", sig)
+        return self._pack
+
     def match(self, dense_pm, dense_fm, dense_po, dense_fo, radius, model):
         """The post-feature-extraction seam (pose_estimation_model.py:29-55): the hot path proper."""
+        if self.fused and self.coarse_npoint == 196:
+            if self.training:
+                raise RuntimeError("inference only: call .eval() (the reference fork is inference-only too, README.md:78-84)")
+            W = self._whole_weights()
+            rand = self.coarse_point_matching.hypothesis_rand
+            if rand is None:
+                rand = torch.rand(dense_pm.shape[0], self.coarse_point_matching.cfg.nproposal1 * 3, device=dense_pm.device)
+            cfg = _cfg_dict(self.coarse_point_matching.cfg, _cfg_dict(self.fine_point_matching.cfg))
+            cfg.update(coarse_npoint=self.coarse_npoint, sigma_d=self.geo_embedding.sigma_d, sigma_a=self.geo_embedding.sigma_a,
+                       angle_k=self.geo_embedding.angle_k)
+            return _pem.pem_match(dense_pm.contiguous(), dense_fm.contiguous(), dense_po.contiguous(), dense_fo.contiguous(),
+                                  radius.reshape(-1).contiguous(), model.contiguous(), W, rand.contiguous(), cfg=cfg)
         bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device) * 100
         sparse_pm, sparse_fm, fps_idx_m = sample_pts_feats(dense_pm, dense_fm, self.coarse_npoint, return_index=True)
         geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm], dim=1))

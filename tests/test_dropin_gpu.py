@@ -33,10 +33,17 @@ def test_net_match_known_answer(net, dev):
     inp = synth.kat_inputs(B=2, seed=int(g["kat_seed"]))
     d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
     net.coarse_point_matching.hypothesis_rand = d["rand"]
-    with torch.no_grad():
-        R, t, s = net.match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"])
-    net.coarse_point_matching.hypothesis_rand = None
-    _close(R, g["kat_R"], 1e-4, "pred_R"); _close(t, g["kat_t"], 1e-4, "pred_t"); _close(s, g["kat_score"], 1e-4, "score")
+    try:
+        for fused in (True, False):  # one fused pipeline / module by module through the reference's call graph
+            net.fused = fused
+            with torch.no_grad():
+                R, t, s = net.match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"])
+            tag = " (fused=%s)" % fused
+            _close(R, g["kat_R"], 1e-4, "pred_R" + tag); _close(t, g["kat_t"], 1e-4, "pred_t" + tag)
+            _close(s, g["kat_score"], 1e-4, "score" + tag)
+    finally:
+        net.coarse_point_matching.hypothesis_rand = None
+        net.fused = True
 
 
 def test_pointnet2_utils_call_sites(dev):
