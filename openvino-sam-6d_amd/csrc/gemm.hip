@@ -42,7 +42,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   W += (size_t)bz * sW + (size_t)bi * b2.sW2;
   C += (size_t)bz * sC + (size_t)bi * b2.sC2;
   if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The tiles_n column
+  // tiles of one row tile get ids 8 apart (same XCD, dispatched together), so the A rows they share come from HBM once
+  // and from that XCD's L2 afterwards; eight consecutive row tiles form a group of 8 * tiles_n ids.
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  int tm_, tn_;
+  if (tiles_n <= 8 && tiles_m >= 32) {  // (small problems: plain order, no padding, every XCD gets tiles)
+    const int g = blockIdx.x / (8 * tiles_n), r = blockIdx.x % (8 * tiles_n);
+    tm_ = g * 8 + (r & 7);
+    tn_ = r >> 3;
+    if (tm_ >= tiles_m) return;  // padding of the last group (uniform for the workgroup)
+  } else {
+    tm_ = blockIdx.x % tiles_m;
+    tn_ = blockIdx.x / tiles_m;
+  }
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
   f32x16 acc[TM][TN];
@@ -189,7 +203,21 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   W += (size_t)bz * sW + (size_t)bi * b2.sW2;
   C += (size_t)bz * sC + (size_t)bi * b2.sC2;
   if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The tiles_n column
+  // tiles of one row tile get ids 8 apart (same XCD, dispatched together), so the A rows they share come from HBM once
+  // and from that XCD's L2 afterwards; eight consecutive row tiles form a group of 8 * tiles_n ids.
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  int tm_, tn_;
+  if (tiles_n <= 8 && tiles_m >= 32) {  // (small problems: plain order, no padding, every XCD gets tiles)
+    const int g = blockIdx.x / (8 * tiles_n), r = blockIdx.x % (8 * tiles_n);
+    tm_ = g * 8 + (r & 7);
+    tn_ = r >> 3;
+    if (tm_ >= tiles_m) return;  // padding of the last group (uniform for the workgroup)
+  } else {
+    tm_ = blockIdx.x % tiles_m;
+    tn_ = blockIdx.x / tiles_m;
+  }
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
   f32x16 acc[TM][TN];
@@ -382,8 +410,11 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   const int nz = batch * b2.n2;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * nz;
   const bool big = blocks128 >= 1024;  // >= 4 workgroups per CU: big tiles
-  dim3 grid(cdiv(M, big ? 128 : 64), cdiv(N, big ? 128 : 64), nz);  // M tiles on x (2^31 limit)
-  SAM6D_REQUIRE(grid.y <= 65535, "gemm_nt: N too large for one launch (%d)", N);
+  const int tm = cdiv(M, big ? 128 : 64), tn = cdiv(N, big ? 128 : 64);
+  // all tiles on x (2^31 limit) in the XCD-aware order the kernels decode; groups of 8 row tiles are padded
+  const long tiles = (tn <= 8 && tm >= 32) ? (long)cdiv(tm, 8) * 8 * tn : (long)tm * tn;
+  SAM6D_REQUIRE(tiles < 2147483647L, "gemm_nt: too many tiles for one launch");
+  dim3 grid((unsigned)tiles, 1, nz);
   hipStream_t st = (hipStream_t)stream;
 #define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
