@@ -126,6 +126,9 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             traffic = tj["kernels"][kname if fused else "geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if B == B_PER_GPU else None
+            if traffic is not None and fused:  # recorded for a 64-cloud launch; a micro-batch slice moves its share
+                mbk = int(os.environ.get("SAM6D_MICROBATCH", "2"))
+                traffic = traffic // (mbk if (mbk > 1 and B >= 8 * mbk) else 1)
         except Exception:
             traffic = None
         if fused:
@@ -133,13 +136,17 @@ def main():
             # contraction the kernel is formulated as (fp32-equivalent flops; every product costs 3 fp16 MFMA products, so the
             # bound is the dense fp16 MFMA peak / 3).  The reference computes the same scores with proj_p on a materialised
             # embedding: 5.09 GFLOP per cloud and layer plus a sixth of the 20.35 GFLOP embedding -- reported beside it.
-            flop = 2 * B * 197 * RPE_FLOP_PER_QUERY
+            mb = int(os.environ.get("SAM6D_MICROBATCH", "2"))
+            mb = mb if (mb > 1 and B >= 8 * mb) else 1
+            clouds = 2 * ((B + mb - 1) // mb)  # the batch runs as `mb` slices on `mb` streams: one launch covers one slice
+            flop = clouds * 197 * RPE_FLOP_PER_QUERY
             achieved = flop / (k_ms * 1e-3) / 1e12 if ev else None
             peak = PEAK_FP16_MFMA_TFLOPS / 3.0
-            ref_flop = 2 * B * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
+            ref_flop = clouds * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
             roofline = {"bound": "mfma",
                         "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16x3 split = 3 MFMA products per fp32 product), "
-                                  "one RPE layer over 2B clouds per launch, 6 launches per step",
+                                  "one RPE layer over %d clouds per launch, %d launches per step on %d concurrent streams "
+                                  "(durations include the other stream's kernels)" % (clouds, 6 * mb, mb),
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": flop / 1e9,

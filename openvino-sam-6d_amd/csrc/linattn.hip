@@ -84,22 +84,24 @@ __global__ __launch_bounds__(256) void kv_reduce_kernel(const float* __restrict_
 // q rows: phi() then scale head h by z = 1 / (phi(q)_h . ksum_h + 1e-6)
 __global__ __launch_bounds__(256) void focus_q_kernel(float* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ ksum, long rows_per_b, long rows, long ld) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const long b = row / rows_per_b;
+  // softplus(scale) costs as much as the rest of a row: each wave computes it once and walks rows with a grid stride
   const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
   const float4 sp = make_float4(softplus_f(sc.x), softplus_f(sc.y), softplus_f(sc.z), softplus_f(sc.w));
-  float4* p = reinterpret_cast<float4*>(x + row * ld + lane * 4);
-  float4 q = focus_row(*p, sp);
-  const float4 ksv = *reinterpret_cast<const float4*>(ksum + b * 256 + lane * 4);  // [b][h][64] == [b][256]
-  float dot = (q.x * ksv.x + q.y * ksv.y) + (q.z * ksv.z + q.w * ksv.w);
-  dot += __shfl_xor(dot, 1, 64);
-  dot += __shfl_xor(dot, 2, 64);
-  dot += __shfl_xor(dot, 4, 64);
-  dot += __shfl_xor(dot, 8, 64);  // 16-lane group == one head
-  const float z = 1.0f / (dot + 1e-6f);
-  *p = make_float4(q.x * z, q.y * z, q.z * z, q.w * z);
+  const long stride = (long)gridDim.x * 4;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += stride) {
+    const long b = row / rows_per_b;
+    float4* p = reinterpret_cast<float4*>(x + row * ld + lane * 4);
+    float4 q = focus_row(*p, sp);
+    const float4 ksv = *reinterpret_cast<const float4*>(ksum + b * 256 + lane * 4);  // [b][h][64] == [b][256]
+    float dot = (q.x * ksv.x + q.y * ksv.y) + (q.z * ksv.z + q.w * ksv.w);
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    dot += __shfl_xor(dot, 8, 64);  // 16-lane group == one head
+    const float z = 1.0f / (dot + 1e-6f);
+    *p = make_float4(q.x * z, q.y * z, q.z * z, q.w * z);
+  }
 }
 
 extern "C" int sam6d_linattn_focus_k(float* k, const float* scale, long rows, long ld, void* stream) {
@@ -122,7 +124,9 @@ extern "C" int sam6d_linattn_focus_q(float* q, const float* scale, const float* 
   SAM6D_REQUIRE(q && scale && ksum && B >= 0 && rows_per_b > 0 && ld >= 256 && (ld & 3) == 0, "linattn_focus_q: bad arguments");
   if (B == 0) return 0;
   const long rows = (long)B * rows_per_b;
-  hipLaunchKernelGGL(focus_q_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, scale, ksum,
-                     rows_per_b, rows, ld);
+  long blocks = (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;  // 16 workgroups per CU, 8 rows per wave at the dense size
+  hipLaunchKernelGGL(focus_q_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, q, scale, ksum, rows_per_b, rows,
+                     ld);
   SAM6D_LAUNCH_CHECK("linattn_focus_q");
 }

@@ -627,10 +627,12 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
 _SIDE_STREAMS = {}
 
 
-def _side_stream(dev):
-    s = _SIDE_STREAMS.get(dev)
+def _side_stream(dev, key=0):
+    """A per-device pool of auxiliary HIP streams (key 0: the side stream of the default pipeline; ("mb", i) the micro-batch
+    streams and ("mb", i, "side") their side streams)."""
+    s = _SIDE_STREAMS.get((dev, key))
     if s is None:
-        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        s = _SIDE_STREAMS[(dev, key)] = torch.cuda.Stream(device=dev)
     return s
 
 
@@ -641,8 +643,43 @@ DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0
 def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False):
     """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
-    rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292)."""
+    rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
+
+    Proposals are independent, and a third of the step is chains of small launches (197-token layers, hypothesis scoring) that
+    cannot fill the chip on their own: with cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 2 for B >= 16) the batch is
+    cut into k slices that run the same pipeline on k HIP streams, so one slice's latency-bound chain sits beside another's
+    dense kernels.  Results do not depend on k (every kernel treats proposals independently)."""
     B = dense_pm.shape[0]
+    mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "2")))
+    if mb > 1 and B >= 8 * mb and not return_aux and cfg.get("_slice") is None:
+        main = torch.cuda.current_stream()
+        if _lib.load().sam6d_get_matmul_mode() == 1:
+            geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
+        sub = dict(cfg, _slice=True)
+        outs = []
+        per = (B + mb - 1) // mb
+        for i in range(mb):
+            lo, hi = i * per, min(B, (i + 1) * per)
+            st = _side_stream(dense_pm.device, ("mb", i))
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                sub["_side_key"] = ("mb", i, "side")
+                o = pem_match(dense_pm[lo:hi], dense_fm[lo:hi], dense_po[lo:hi], dense_fo[lo:hi], radius[lo:hi], model[lo:hi], W,
+                              rand[lo:hi], sub)
+            outs.append(o)
+        R = _empty((B, 3, 3), dense_pm)
+        t = _empty((B, 3), dense_pm)
+        sc = _empty((B,), dense_pm)
+        for i, o in enumerate(outs):
+            lo = i * per
+            st = _side_stream(dense_pm.device, ("mb", i))
+            main.wait_stream(st)
+            for dst, src, w in ((R, o[0], 9), (t, o[1], 3), (sc, o[2], 1)):
+                src.record_stream(main)
+                _lib.call("sam6d_copy_f32", _p(src), _p(dst, lo * w), src.numel(), _s())
+        return R, t, sc
+    dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
+    radius, model, rand = radius.contiguous(), model.contiguous(), rand.contiguous()
     dp = _cat0(dense_pm, dense_po)
     df = _cat0(dense_fm, dense_fo)
     n = cfg["coarse_npoint"]
@@ -660,7 +697,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     D = None
     if cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1"):
         main = torch.cuda.current_stream()
-        side = _side_stream(dp.device)
+        side = _side_stream(dp.device, cfg.get("_side_key", 0))
         side.wait_stream(main)
         with torch.cuda.stream(side):
             D = fine_static(dp, df, W, cfg)
