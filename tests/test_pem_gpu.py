@@ -529,6 +529,21 @@ def test_pem_match_fused_vs_materialised(dev, W):
         _close(b, e, 1e-4, "pem_match materialised (Chebyshev) vs exact-fp32 mode: " + what)
 
 
+def test_pem_match_microbatch_invariance(dev, W):
+    """Proposals are independent: running the batch as 1, 2 or 3 slices on separate HIP streams must not change a bit."""
+    from sam6d_hip import pem, synth
+    inp = synth.config2_inputs(B=24, seed=5)
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    outs = []
+    for mb in (1, 2, 3):
+        cfg = dict(pem.DEFAULT_CFG, microbatch=mb)
+        outs.append([o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
+                                                    d["model"], W, d["rand"], cfg=cfg)])
+    for o in outs[1:]:
+        for a, b, what in zip(outs[0], o, ("R", "t", "score")):
+            assert torch.equal(a, b), "micro-batched %s differs: %.3e" % (what, float((a - b).abs().max()))
+
+
 def test_config5_shape_4096_points(dev, W, sd):
     """BASELINE config 5's geometry (fine_npoint = 4096): the whole path at N = 4096 dense points, B = 1, against the CPU
     oracle (fp32; the config's fp16 attention variant is a later round)."""
