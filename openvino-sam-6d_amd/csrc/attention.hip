@@ -70,15 +70,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         // keep heads {0,1} in lanes 0-31 and {2,3} in lanes 32-63
         const float s0 = hi32 ? sp[0] : sp[2], s1 = hi32 ? sp[1] : sp[3];  // what the partner half needs
         const float k0 = hi32 ? sp[2] : sp[0], k1 = hi32 ? sp[3] : sp[1];
-        const float pa = k0 + __shfl_xor(s0, 32, 64), pb = k1 + __shfl_xor(s1, 32, 64);
+        const float pa = k0 + xor32_f32(s0), pb = k1 + xor32_f32(s1);
         // keep the even head of the pair in lanes with bit4 = 0, the odd one in lanes with bit4 = 1
         const float send = hi16 ? pa : pb, keep = hi16 ? pb : pa;
-        se += keep + __shfl_xor(send, 16, 64);  // lane group (lane>>4) now carries head (lane>>4) of both terms
+        se += keep + xor16_f32(send);  // lane group (lane>>4) now carries head (lane>>4) of both terms
       }
-      se += __shfl_xor(se, 1, 64);
-      se += __shfl_xor(se, 2, 64);
-      se += __shfl_xor(se, 4, 64);
-      se += __shfl_xor(se, 8, 64);
+      se = row16_sum_dpp(se);  // 4 DPP adds (row_ror 8/4/2/1) instead of 4 LDS-crossbar shuffles
       if ((lane & 15) == 0 && j < m) s_s[lane >> 4][j] = se * scale;
     }
   }
@@ -86,14 +83,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   {  // softmax of head `wave` over m (F.softmax: exp(x - max) / sum)
     float mx = -INFINITY;
     for (int j = lane; j < m; j += 64) mx = fmaxf(mx, s_s[wave][j]);
-    mx = wave_max(mx);
+    mx = wave_max_dpp(mx);
     float sum = 0.f;
     for (int j = lane; j < m; j += 64) {
       const float e = expf(s_s[wave][j] - mx);
       s_s[wave][j] = e;
       sum += e;
     }
-    sum = wave_sum(sum);
+    sum = wave_sum_dpp(sum);
     const float inv = 1.0f / sum;
     for (int j = lane; j < m; j += 64) s_s[wave][j] *= inv;
   }

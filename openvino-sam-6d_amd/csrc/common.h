@@ -66,6 +66,52 @@ __device__ __forceinline__ float wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// ---- DPP / permlane reductions (no LDS crossbar: ds_bpermute costs an LDS round trip per step, these are plain VALU).
+// The summation ORDER differs from the xor butterfly above, so results can differ in the last bit: use them where no bit
+// recipe of the reference is pinned (attention, LayerNorm, focus, norms); max / min are order-independent.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over each 16-lane row: rotations by 8, 4, 2, 1 (row_ror) -- every lane ends with the row total
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+  v += dpp_f32<0x128>(v);  // row_ror:8
+  v += dpp_f32<0x124>(v);  // row_ror:4
+  v += dpp_f32<0x122>(v);  // row_ror:2
+  v += dpp_f32<0x121>(v);  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float row16_max_dpp(float v) {
+  v = fmaxf(v, dpp_f32<0x128>(v));
+  v = fmaxf(v, dpp_f32<0x124>(v));
+  v = fmaxf(v, dpp_f32<0x122>(v));
+  v = fmaxf(v, dpp_f32<0x121>(v));
+  return v;
+}
+// exchange with the lane 16 / 32 away (gfx950 v_permlane16_swap / v_permlane32_swap on a copy)
+__device__ __forceinline__ float xor16_f32(float v) {
+  typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+  const u2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor32_f32(float v) {
+  typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+  const u2_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum_dpp(v);
+  v += xor16_f32(v);
+  v += xor32_f32(v);
+  return v;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = row16_max_dpp(v);
+  v = fmaxf(v, xor16_f32(v));
+  v = fmaxf(v, xor32_f32(v));
+  return v;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

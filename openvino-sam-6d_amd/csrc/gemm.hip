@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float4 v = *reinterpret_cast<const float4*>(x + row * ldx + lane * 4);
-  const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+  const float mean = wave_sum_dpp((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
   const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-  const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 256.0f);
+  const float var = wave_sum_dpp((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 256.0f);
   const float rstd = 1.0f / sqrtf(var + eps);
   const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
   const float4 bb = *reinterpret_cast<const float4*>(b + lane * 4);

@@ -26,8 +26,8 @@ __device__ __forceinline__ float4 focus_row(float4 x, const float4 sp) {
     c[u] = (v * v) * v;
     n3 += c[u] * c[u];
   }
-  n1 = sqrtf(wave_sum(n1));
-  n3 = sqrtf(wave_sum(n3));
+  n1 = sqrtf(wave_sum_dpp(n1));
+  n3 = sqrtf(wave_sum_dpp(n3));
   return make_float4((c[0] / n3) * n1, (c[1] / n3) * n1, (c[2] / n3) * n1, (c[3] / n3) * n1);
 }
 
@@ -95,10 +95,7 @@ __global__ __launch_bounds__(256) void focus_q_kernel(float* __restrict__ x, con
     float4 q = focus_row(*p, sp);
     const float4 ksv = *reinterpret_cast<const float4*>(ksum + b * 256 + lane * 4);  // [b][h][64] == [b][256]
     float dot = (q.x * ksv.x + q.y * ksv.y) + (q.z * ksv.z + q.w * ksv.w);
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    dot += __shfl_xor(dot, 4, 64);
-    dot += __shfl_xor(dot, 8, 64);  // 16-lane group == one head
+    dot = row16_sum_dpp(dot);  // 16-lane group == one head
     const float z = 1.0f / (dot + 1e-6f);
     *p = make_float4(q.x * z, q.y * z, q.z * z, q.w * z);
   }

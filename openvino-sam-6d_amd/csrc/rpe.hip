@@ -277,10 +277,10 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
           const int pj = __shfl(ps_cur, j, 64);
           const float4 e = *reinterpret_cast<const float4*>(rows + (size_t)pj * 256 + lane * 4);
           float sp[4];
-          sp[0] = wave_sum((qf[0].x * e.x + qf[1].x * e.y) + (qf[2].x * e.z + qf[3].x * e.w));
-          sp[1] = wave_sum((qf[0].y * e.x + qf[1].y * e.y) + (qf[2].y * e.z + qf[3].y * e.w));
-          sp[2] = wave_sum((qf[0].z * e.x + qf[1].z * e.y) + (qf[2].z * e.z + qf[3].z * e.w));
-          sp[3] = wave_sum((qf[0].w * e.x + qf[1].w * e.y) + (qf[2].w * e.z + qf[3].w * e.w));
+          sp[0] = wave_sum_dpp((qf[0].x * e.x + qf[1].x * e.y) + (qf[2].x * e.z + qf[3].x * e.w));
+          sp[1] = wave_sum_dpp((qf[0].y * e.x + qf[1].y * e.y) + (qf[2].y * e.z + qf[3].y * e.w));
+          sp[2] = wave_sum_dpp((qf[0].z * e.x + qf[1].z * e.y) + (qf[2].z * e.z + qf[3].z * e.w));
+          sp[3] = wave_sum_dpp((qf[0].w * e.x + qf[1].w * e.y) + (qf[2].w * e.z + qf[3].w * e.w));
           if (lane < 4) {
             const float mine = lane == 0 ? sp[0] : lane == 1 ? sp[1] : lane == 2 ? sp[2] : sp[3];
             scw[lane * mpad + key0 + j] = mine * 1024.0f;
@@ -300,14 +300,14 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
         xv[u] = j < n ? (scw[h * mpad + j] + se[j]) * scale : -INFINITY;
         mx = fmaxf(mx, xv[u]);
       }
-      mx = wave_max(mx);
+      mx = wave_max_dpp(mx);
       float sum = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         xv[u] = lane + 64 * u < n ? expf(xv[u] - mx) : 0.f;
         sum += xv[u];
       }
-      sum = wave_sum(sum);
+      sum = wave_sum_dpp(sum);
       const float inv = 1.0f / sum;
       float* pr = P + (q * 4 + h) * ldp;
 #pragma unroll
