@@ -127,7 +127,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             traffic = tj["kernels"][kname if fused else "geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if B == B_PER_GPU else None
             if traffic is not None and fused:  # recorded for a 64-cloud launch; a micro-batch slice moves its share
-                mbk = int(os.environ.get("SAM6D_MICROBATCH", "2"))
+                mbk = int(os.environ.get("SAM6D_MICROBATCH", "1"))
                 traffic = traffic // (mbk if (mbk > 1 and B >= 8 * mbk) else 1)
         except Exception:
             traffic = None
@@ -136,7 +136,7 @@ def main():
             # contraction the kernel is formulated as (fp32-equivalent flops; every product costs 3 fp16 MFMA products, so the
             # bound is the dense fp16 MFMA peak / 3).  The reference computes the same scores with proj_p on a materialised
             # embedding: 5.09 GFLOP per cloud and layer plus a sixth of the 20.35 GFLOP embedding -- reported beside it.
-            mb = int(os.environ.get("SAM6D_MICROBATCH", "2"))
+            mb = int(os.environ.get("SAM6D_MICROBATCH", "1"))
             mb = mb if (mb > 1 and B >= 8 * mb) else 1
             clouds = 2 * ((B + mb - 1) // mb)  # the batch runs as `mb` slices on `mb` streams: one launch covers one slice
             flop = clouds * 197 * RPE_FLOP_PER_QUERY

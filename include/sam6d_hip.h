@@ -128,12 +128,13 @@ int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, fl
  * sam6d_rpe_scores: P[q][h][0..n) (row stride ldp) = softmax_m((qk[q][h][m] + qp[q][h][:] . E[q][m][:]) / 8) for the Q = B*n
  *   queries, E rebuilt per key tile from the 32-term Chebyshev basis (wa_cheb = the proj_a half of the sam6d_geo_embed_cheb
  *   image; qd[q][h][0..32) = D_c^T qp[q][h], D_c = Chebyshev coefficients of proj_d) or read from `rows` for listed pairs.
- *   qp (Q,4,256) = proj_p folded into the query (see sam6d_attention), qk (Q,4,ldp) = q_h . k_h[m].
+ *   qp (Q,4,256) = proj_p folded into the query (see sam6d_attention), qk (Q,4,ldp) = q_h . k_h[m]; qk is updated in place
+ *   (the geometric term of the listed pairs is added to it first, one wave per pair of list_ws).
  * sam6d_transpose: dst[b][c][j] = src[b][j][c] (the values as the N x K operand of the P.V GEMM). */
 int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, const float* div_term, const void* w_packed, const float* Wd,
                        const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows, void* stream);
-int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const float* rows, const void* wa_cheb, float xmax, const float* qp,
-                     const float* qd, const float* qk, float* P, long Q, int n, int ldp, void* stream);
+int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb, float xmax,
+                     const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp, void* stream);
 int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n, int ncol, float* dst, long ld_dst,
                     long stride_dst, void* stream);
 

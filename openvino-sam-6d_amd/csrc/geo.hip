@@ -381,6 +381,10 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
 
 
 // pos[pair] = -1 when all four indices of the pair lie in [0, xmax] (Chebyshev range), else its slot in list[1..]; list[0] = count
+// zeroes the list counter.  A kernel, not hipMemsetAsync: the fill must be ordered with the atomics of the next kernel like any
+// other launch on the stream
+__global__ void geo_list_reset_kernel(int* __restrict__ list) { list[0] = 0; }
+
 __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax,
                                                            int* __restrict__ pos, int* __restrict__ list) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -551,8 +555,7 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
     n_cu = cu;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(list_ws, 0, sizeof(int), s);
-  SAM6D_REQUIRE(e == hipSuccess, "geo_embed_cheb: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb(classify)");
@@ -580,8 +583,7 @@ extern "C" int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, c
   if (pairs == 0) return 0;
   if (int rc = h3_reserve_lds()) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(list_ws, 0, sizeof(int), s);
-  SAM6D_REQUIRE(e == hipSuccess, "geo_outliers: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_outliers(classify)");

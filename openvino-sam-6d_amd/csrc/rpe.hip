@@ -103,7 +103,6 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       const bool valid = key < n;
       const bool listed = valid && ps >= 0;
       const unsigned listed_mask = (unsigned)(__ballot(listed && kg == 0) & 0xffffull);
-      const int ps_cur = ps;
       // ---- basis: one recurrence per lane, then the 4 x 4 transpose over the lane rows
       float R[4][8];
       {
@@ -265,27 +264,10 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
         if (key0 + row < n && !((listed_mask >> row) & 1u)) scw[h * mpad + key0 + row] += z;
       }
 
-      // ---- listed keys: the whole wave dots the stored embedding row with the 4 folded queries (from the LDS copy)
-      if (listed_mask) {  // wave-uniform
-        float4 qf[4];  // qf[i] = (h0, h1, h2, h3) of channel 4 lane + i, scaled by 1/1024
+      // listed keys (outside the Chebyshev range): their geometric term was added to the q.k scores by rpe_listed_kernel
+      if (listed && kg == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const float4*>(qw + (lane * 4 + i) * 4);
-        unsigned mk = listed_mask;
-        while (mk) {
-          const int j = __builtin_ctz(mk);
-          mk &= mk - 1;
-          const int pj = __shfl(ps_cur, j, 64);
-          const float4 e = *reinterpret_cast<const float4*>(rows + (size_t)pj * 256 + lane * 4);
-          float sp[4];
-          sp[0] = wave_sum_dpp((qf[0].x * e.x + qf[1].x * e.y) + (qf[2].x * e.z + qf[3].x * e.w));
-          sp[1] = wave_sum_dpp((qf[0].y * e.x + qf[1].y * e.y) + (qf[2].y * e.z + qf[3].y * e.w));
-          sp[2] = wave_sum_dpp((qf[0].z * e.x + qf[1].z * e.y) + (qf[2].z * e.z + qf[3].z * e.w));
-          sp[3] = wave_sum_dpp((qf[0].w * e.x + qf[1].w * e.y) + (qf[2].w * e.z + qf[3].w * e.w));
-          if (lane < 4) {
-            const float mine = lane == 0 ? sp[0] : lane == 1 ? sp[1] : lane == 2 ? sp[2] : sp[3];
-            scw[lane * mpad + key0 + j] = mine * 1024.0f;
-          }
-        }
+        for (int h = 0; h < 4; ++h) scw[h * mpad + key] = 0.f;
       }
     }
     // ---- softmax over the keys (F.softmax: exp(x - max) / sum) of (q.k + geometric term) / 8, probabilities to P[q][h][:]
@@ -319,10 +301,37 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
   }
 }
 
-extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const float* rows, const void* wa_cheb, float xmax,
-                                const float* qp, const float* qd, const float* qk, float* P, long Q, int n, int ldp,
+// Geometric score term of the listed pairs (an index outside [0, xmax]: the bg token, 2n-1 of n^2 pairs): one wave per pair
+// dots its stored bias-free embedding row with the 4 folded queries and adds the result to the q.k score of that (query, head,
+// key).  Runs between the q.k^T GEMM and rpe_score_kernel; each score element is touched by at most one wave.
+__global__ __launch_bounds__(256) void rpe_listed_kernel(const int* __restrict__ list, const float* __restrict__ rows,
+                                                         const float* __restrict__ qp, float* __restrict__ Se, int n, int ldp) {
+  const int lane = threadIdx.x & 63;
+  const int count = list[0];
+  const int stride = gridDim.x * 4;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += stride) {
+    const int e = list[1 + i];
+    const long q = e / n;
+    const int m = e - (int)q * n;
+    const float4 r = *reinterpret_cast<const float4*>(rows + (size_t)i * 256 + lane * 4);
+    const float* qpq = qp + q * 1024 + lane * 4;
+    float sp[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float4 w = *reinterpret_cast<const float4*>(qpq + h * 256);
+      sp[h] = wave_sum_dpp((w.x * r.x + w.y * r.y) + (w.z * r.z + w.w * r.w));
+    }
+    if (lane < 4) {
+      const float mine = lane == 0 ? sp[0] : lane == 1 ? sp[1] : lane == 2 ? sp[2] : sp[3];
+      Se[(q * 4 + lane) * ldp + m] += mine;
+    }
+  }
+}
+
+extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
+                                float xmax, const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp,
                                 void* stream) {
-  SAM6D_REQUIRE(idx_ws && pos_ws && rows && wa_cheb && qp && qd && qk && P, "rpe_scores: null pointer");
+  SAM6D_REQUIRE(idx_ws && pos_ws && list_ws && rows && wa_cheb && qp && qd && qk && P, "rpe_scores: null pointer");
   SAM6D_REQUIRE(Q >= 0 && n > 0 && n <= RP_MAXM && ldp >= n, "rpe_scores: need 0 < n <= %d and ldp >= n (n = %d, ldp = %d)",
                 RP_MAXM, n, ldp);
   SAM6D_REQUIRE(xmax > 0.f, "rpe_scores: xmax must be positive");
@@ -350,6 +359,10 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const fl
   if (waves > 12) waves = 12;  // 3 waves per SIMD: 170 registers per lane, no spills
   long blocks = (Q + waves - 1) / waves;
   if (blocks > n_cu) blocks = n_cu;
+  long lblocks = (Q * 2 + 3) / 4;  // about two listed pairs per query token (its bg key and its share of the bg query)
+  if (lblocks > 4096) lblocks = 4096;
+  hipLaunchKernelGGL(rpe_listed_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, list_ws, rows, qp, qk, n, ldp);
+  SAM6D_LAUNCH_CHECK_CONT("rpe_scores(listed pairs)");
   hipLaunchKernelGGL(rpe_score_kernel, dim3((unsigned)blocks), dim3(64 * waves), RP_WBYTES + waves * per_wave,
                      (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), pos_ws, rows,
                      reinterpret_cast<const unsigned char*>(wa_cheb), qp, qd, qk, P, n, ldp, Q, xmax, scale, mpad);

@@ -358,8 +358,8 @@ def rpe_self_layer_fused(x, G, L):
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
     P = _empty((M, H, ldp), x)
     with _Timed("rpe_score_kernel"):
-        _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd), _p(qk), _p(P),
-                  M, n, ldp, _s())
+        _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd),
+                  _p(qk), _p(P), M, n, ldp, _s())
     vT = _empty((Bp, C, ldp), x)
     _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())
     hid = _empty((M, C), x)
@@ -645,12 +645,14 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
 
-    Proposals are independent, and a third of the step is chains of small launches (197-token layers, hypothesis scoring) that
-    cannot fill the chip on their own: with cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 2 for B >= 16) the batch is
-    cut into k slices that run the same pipeline on k HIP streams, so one slice's latency-bound chain sits beside another's
-    dense kernels.  Results do not depend on k (every kernel treats proposals independently)."""
+    cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 1 = off): EXPERIMENTAL.  The batch is cut into k slices that run the
+    same pipeline on k HIP streams (one slice's latency-bound chains beside another's dense kernels: +5 % at k = 2).  It is off
+    by default because two instances of the pipeline running concurrently are NOT yet bit-reproducible on MI355X: about a third
+    of the k = 2 runs differ from the serial result (scratch/dbg_ov.py; the single pipeline with its side stream: 0 of 150).
+    The cause is not found; suspects are the persistent large-LDS kernels of the split-precision mode (the exact-fp32 mode shows
+    no mismatch in 30 runs at k = 3).  Do not enable it for results that matter."""
     B = dense_pm.shape[0]
-    mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "2")))
+    mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
     if mb > 1 and B >= 8 * mb and not return_aux and cfg.get("_slice") is None:
         main = torch.cuda.current_stream()
         if _lib.load().sam6d_get_matmul_mode() == 1:

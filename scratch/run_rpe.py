@@ -32,8 +32,8 @@ qk = pem._empty((M, H, ldp), x)
 pem.gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
 P = pem._empty((M, H, ldp), x)
 def run():
-    _lib.call("sam6d_rpe_scores", pem._p(G.idx), pem._p(G.pos), pem._p(G.rows), G.wa_cheb, float(pem.GEO_XMAX), pem._p(qp), pem._p(qd),
-              pem._p(qk), pem._p(P), M, n, ldp, pem._s())
+    _lib.call("sam6d_rpe_scores", pem._p(G.idx), pem._p(G.pos), pem._p(G.keep[1]), pem._p(G.rows), G.wa_cheb, float(pem.GEO_XMAX),
+              pem._p(qp), pem._p(qd), pem._p(qk), pem._p(P), M, n, ldp, pem._s())
 for _ in range(3): run()
 torch.cuda.synchronize()
 a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
