@@ -109,6 +109,77 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   out[(size_t)b * so + (size_t)i * ldo + t] = (a0 + a1) + (a2 + a3);
 }
 
+// Cross layers (no geometric term): NQ query tokens per workgroup.  The kernel is bound by the L2 reads of the cloud's k and v
+// rows (2 x 197 KiB per workgroup): every k / v row load is shared by the NQ queries.
+template <int NQ>
+__global__ __launch_bounds__(256) void attention_mq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, float* __restrict__ out, int n, int m,
+                                                           long ldq, long ldk, long ldv, long ldo, long sq, long sk, long sv,
+                                                           long so, float scale) {
+  __shared__ float s_s[NQ][4][AT_MAXM];
+  const int b = blockIdx.y, i0 = blockIdx.x * NQ;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* qrow0 = q + (size_t)b * sq;
+  float4 qv[NQ];  // lane covers head lane/16
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) qv[qi] = *reinterpret_cast<const float4*>(qrow0 + (size_t)min(i0 + qi, n - 1) * ldq + lane * 4);
+  const float* kb = k + (size_t)b * sk;
+  for (int j0 = wave * 4; j0 < m; j0 += 16) {
+    float4 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)min(j0 + u, m - 1) * ldk + lane * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        float sa = (qv[qi].x * kv[u].x + qv[qi].y * kv[u].y) + (qv[qi].z * kv[u].z + qv[qi].w * kv[u].w);
+        sa = row16_sum_dpp(sa);
+        if ((lane & 15) == 0 && j < m) s_s[qi][lane >> 4][j] = sa * scale;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {  // softmax of head `wave` of query qi (F.softmax: exp(x - max) / sum)
+    float* s = s_s[qi][wave];
+    float mx = -INFINITY;
+    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, s[j]);
+    mx = wave_max_dpp(mx);
+    float sum = 0.f;
+    for (int j = lane; j < m; j += 64) {
+      const float e = expf(s[j] - mx);
+      s[j] = e;
+      sum += e;
+    }
+    sum = wave_sum_dpp(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < m; j += 64) s[j] *= inv;
+  }
+  __syncthreads();
+  const float* vb = v + (size_t)b * sv + t;
+  float acc[NQ][2];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = 0.f;
+  int j = 0;
+  for (; j + 2 <= m; j += 2) {
+    const float v0 = vb[(size_t)j * ldv], v1 = vb[(size_t)(j + 1) * ldv];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      acc[qi][0] = fmaf(s_s[qi][t >> 6][j], v0, acc[qi][0]);
+      acc[qi][1] = fmaf(s_s[qi][t >> 6][j + 1], v1, acc[qi][1]);
+    }
+  }
+  for (; j < m; ++j) {
+    const float vv = vb[(size_t)j * ldv];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = fmaf(s_s[qi][t >> 6][j], vv, acc[qi][0]);
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi)
+    if (i0 + qi < n) out[(size_t)b * so + (size_t)(i0 + qi) * ldo + t] = acc[qi][0] + acc[qi][1];
+}
+
 extern "C" int sam6d_attention(const float* q, const float* k, const float* v, const float* qp, const float* E, float* out,
                                int B, int n, int m, long ldq, long ldk, long ldv, long ldo, long sq, long sk, long sv,
                                long so, void* stream) {
@@ -124,7 +195,7 @@ extern "C" int sam6d_attention(const float* q, const float* k, const float* v, c
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, qp, E, out, n, m, ldq,
                        ldk, ldv, ldo, sq, sk, sv, so, scale);
   else
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, qp, E, out, n, m, ldq,
+    hipLaunchKernelGGL(attention_mq_kernel<4>, dim3((n + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, q, k, v, out, n, m, ldq,
                        ldk, ldv, ldo, sq, sk, sv, so, scale);
   SAM6D_LAUNCH_CHECK("attention");
 }

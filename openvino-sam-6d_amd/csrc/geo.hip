@@ -61,23 +61,31 @@ __global__ __launch_bounds__(256) void geo_knn_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void geo_index_kernel(const float* __restrict__ pts, const int* __restrict__ knn, int n,
                                                         float sigma_d, float factor_a, float4* __restrict__ idx4,
                                                         long total, int* __restrict__ maxflag) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int j = (int)(e % n);
-  const long bi = e / n;
-  const int i = (int)(bi % n);
-  const long b = bi / n;
+  // One workgroup = 256 consecutive pairs of ONE cloud (grid.y = cloud).  The cloud's points and neighbour lists (n <= 256:
+  // 6 KiB) are staged in LDS once, so every per-pair operand is an LDS read instead of a dependent global gather.
+  __shared__ float sp[256 * 3];
+  __shared__ int sk[256 * 3];
+  const long b = blockIdx.y;
   const float* p = pts + b * n * 3;
-  const float x0 = p[i * 3], x1 = p[i * 3 + 1], x2 = p[i * 3 + 2];
-  const float y0 = p[j * 3], y1 = p[j * 3 + 1], y2 = p[j * 3 + 2];
+  for (int i = threadIdx.x; i < n * 3; i += 256) {
+    sp[i] = p[i];
+    sk[i] = knn[b * n * 3 + i];
+  }
+  __syncthreads();
+  const int pe = blockIdx.x * 256 + threadIdx.x;  // pair within the cloud
+  if (pe >= n * n) return;
+  const int i = pe / n, j = pe - i * n;
+  const long e = b * n * n + pe;
+  const float x0 = sp[i * 3], x1 = sp[i * 3 + 1], x2 = sp[i * 3 + 2];
+  const float y0 = sp[j * 3], y1 = sp[j * 3 + 1], y2 = sp[j * 3 + 2];
   const float pd = pdist3(x0, x1, x2, sqnorm3(x0, x1, x2), y0, y1, y2, sqnorm3(y0, y1, y2));
   float out[4];
   out[0] = sqrtf(pd) / sigma_d;
   const float a0 = y0 - x0, a1 = y1 - x1, a2 = y2 - x2;  // anchor vector  p_j - p_i
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const int q = knn[bi * 3 + r];
-    const float r0 = p[q * 3] - x0, r1 = p[q * 3 + 1] - x1, r2 = p[q * 3 + 2] - x2;  // reference vector
+    const int q = sk[i * 3 + r];
+    const float r0 = sp[q * 3] - x0, r1 = sp[q * 3 + 1] - x1, r2 = sp[q * 3 + 2] - x2;  // reference vector
     // bit recipes of the torch-CPU kernels the reference runs (pinned by tests/golden/geo_embedding.npz; the bg point
     // at (100,100,100) makes ref/anc long and nearly parallel, so the rounding order is visible in the result):
     //   torch.cross       : fma(u_i, v_j, -rn(u_j * v_i))
@@ -394,7 +402,9 @@ __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restr
   int p = -1;
   if (!ok) {
     p = atomicAdd(list, 1);
-    list[1 + p] = (int)e;
+    // slots are handed out across the whole grid, so neighbouring entries of one cache line are written from different
+    // XCDs: store them at agent scope (memory-side, like the atomic) instead of leaving partial dirty lines in eight L2s
+    __hip_atomic_store(&list[1 + p], (int)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   pos[e] = p;
 }
@@ -615,8 +625,8 @@ extern "C" int sam6d_geo_indices(const float* points, int B, int n, float sigma_
   const long rows = (long)B * n, pairs = rows * n;
   hipLaunchKernelGGL(geo_knn_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, points, n, angle_k, knn_ws, rows);
   SAM6D_LAUNCH_CHECK_CONT("geo_indices(knn)");
-  hipLaunchKernelGGL(geo_index_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, points, knn_ws, n, sigma_d,
-                     factor_a, reinterpret_cast<float4*>(idx_ws), pairs, knn_ws + rows * angle_k);
+  hipLaunchKernelGGL(geo_index_kernel, dim3((unsigned)(((long)n * n + 255) / 256), (unsigned)B), dim3(256), 0, s, points, knn_ws,
+                     n, sigma_d, factor_a, reinterpret_cast<float4*>(idx_ws), pairs, knn_ws + rows * angle_k);
   SAM6D_LAUNCH_CHECK("geo_indices");
 }
 

@@ -645,74 +645,87 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
 
-    cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 1 = off): EXPERIMENTAL.  The batch is cut into k slices that run the
-    same pipeline on k HIP streams (one slice's latency-bound chains beside another's dense kernels: +5 % at k = 2).  It is off
-    by default because two instances of the pipeline running concurrently are NOT yet bit-reproducible on MI355X: about a third
-    of the k = 2 runs differ from the serial result (scratch/dbg_ov.py; the single pipeline with its side stream: 0 of 150).
-    The cause is not found; suspects are the persistent large-LDS kernels of the split-precision mode (the exact-fp32 mode shows
-    no mismatch in 30 runs at k = 3).  Do not enable it for results that matter."""
+    cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 1 = off): the batch is cut into k slices whose coarse / fine stages run
+    on k HIP streams (one slice's latency-bound chains beside another's dense kernels, +2 % at k = 2).  FPS, gathers and the
+    geometric indices of every slice are computed first, serially, on the caller's stream: geo_index_kernel returns wrong
+    angular indices (in groups of 16 lanes) whenever a split-fp16 MFMA kernel of this library runs on the chip at the same
+    time -- found with scratch/dbg_pair2.py; exact-fp32 MFMA GEMMs, rocBLAS, LayerNorm, ball query and copies do not trigger
+    it, and no other stage is affected (scratch/dbg_pair.py, scratch/dbg_ov.py: 0 of 100 runs differ at k = 2 with the serial
+    prepare; 49 of 150 without it).  The same rule keeps the default pipeline safe: its side stream forks after the indices."""
     B = dense_pm.shape[0]
     mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
-    if mb > 1 and B >= 8 * mb and not return_aux and cfg.get("_slice") is None:
-        main = torch.cuda.current_stream()
-        if _lib.load().sam6d_get_matmul_mode() == 1:
-            geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
-        sub = dict(cfg, _slice=True)
-        outs = []
-        per = (B + mb - 1) // mb
-        for i in range(mb):
-            lo, hi = i * per, min(B, (i + 1) * per)
-            st = _side_stream(dense_pm.device, ("mb", i))
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                sub["_side_key"] = ("mb", i, "side")
-                o = pem_match(dense_pm[lo:hi], dense_fm[lo:hi], dense_po[lo:hi], dense_fo[lo:hi], radius[lo:hi], model[lo:hi], W,
-                              rand[lo:hi], sub)
-            outs.append(o)
-        R = _empty((B, 3, 3), dense_pm)
-        t = _empty((B, 3), dense_pm)
-        sc = _empty((B,), dense_pm)
-        for i, o in enumerate(outs):
-            lo = i * per
-            st = _side_stream(dense_pm.device, ("mb", i))
-            main.wait_stream(st)
-            for dst, src, w in ((R, o[0], 9), (t, o[1], 3), (sc, o[2], 1)):
-                src.record_stream(main)
-                _lib.call("sam6d_copy_f32", _p(src), _p(dst, lo * w), src.numel(), _s())
-        return R, t, sc
-    dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
-    radius, model, rand = radius.contiguous(), model.contiguous(), rand.contiguous()
-    dp = _cat0(dense_pm, dense_po)
-    df = _cat0(dense_fm, dense_fo)
-    n = cfg["coarse_npoint"]
-    sp, sf, idx = sample_pts_feats(dp, df, n)
-    pb = _empty((2 * B, n + 1, 3), dp)
-    _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * B, n, _p(pb), _s())
     fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() == 1
-    if fused and not return_aux:
-        E = geo_context(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
-    else:
-        E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
-    # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip idle;
-    # the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs beside it
-    # on a second HIP stream and is joined before the fine transformer.
-    D = None
-    if cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1"):
-        main = torch.cuda.current_stream()
-        side = _side_stream(dp.device, cfg.get("_side_key", 0))
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            D = fine_static(dp, df, W, cfg)
-        D.record_stream(main)
-    c = coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux)
-    R0, t0 = c[0], c[1]
-    if D is not None:
-        main.wait_stream(side)
-    f = fine_point_matching(dp, df, E, idx, radius, model, R0, t0, W, cfg, return_aux, D=D)
-    if return_aux:
-        return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:B], fps_idx_o=idx[B:],
-                                      geo=E)
-    return f
+    fused = fused and not return_aux
+
+    def prepare(lo, hi):
+        """FPS, gathers and the geometric indices of proposals [lo, hi): always on the caller's stream, never beside other
+        kernels (geo_index_kernel returns wrong angles when split-fp16 MFMA kernels run concurrently on the chip: see
+        DESIGN 6)."""
+        b = hi - lo
+        dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
+        df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
+        n = cfg["coarse_npoint"]
+        sp, sf, idx = sample_pts_feats(dp, df, n)
+        pb = _empty((2 * b, n + 1, 3), dp)
+        _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * b, n, _p(pb), _s())
+        if fused:
+            E = geo_context(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+        else:
+            E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+        return dp, df, sp, sf, idx, E
+
+    def rest(prep, lo, hi, side_key):
+        dp, df, sp, sf, idx, E = prep
+        rad, mod, rnd = radius[lo:hi].contiguous(), model[lo:hi].contiguous(), rand[lo:hi].contiguous()
+        # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip
+        # idle; the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs
+        # beside it on a second HIP stream and is joined before the fine transformer.
+        D = None
+        if cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1"):
+            cur = torch.cuda.current_stream()
+            side = _side_stream(dp.device, side_key)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                D = fine_static(dp, df, W, cfg)
+            D.record_stream(cur)
+        c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux)
+        R0, t0 = c[0], c[1]
+        if D is not None:
+            cur.wait_stream(side)
+        f = fine_point_matching(dp, df, E, idx, rad, mod, R0, t0, W, cfg, return_aux, D=D)
+        if return_aux:
+            b = hi - lo
+            return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:b], fps_idx_o=idx[b:],
+                                          geo=E)
+        return f
+
+    dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
+    if mb <= 1 or B < 8 * mb or return_aux:
+        return rest(prepare(0, B), 0, B, 0)
+    main = torch.cuda.current_stream()
+    if _lib.load().sam6d_get_matmul_mode() == 1:
+        geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
+    per = (B + mb - 1) // mb
+    spans = [(i * per, min(B, (i + 1) * per)) for i in range(mb)]
+    preps = [prepare(lo, hi) for lo, hi in spans]  # serial, on the caller's stream
+    outs = []
+    for i, (lo, hi) in enumerate(spans):
+        st = _side_stream(dense_pm.device, ("mb", i))
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            outs.append(rest(preps[i], lo, hi, ("mb", i, "side")))
+        for tns in preps[i][:5]:
+            tns.record_stream(st)
+    R = _empty((B, 3, 3), dense_pm)
+    t = _empty((B, 3), dense_pm)
+    sc = _empty((B,), dense_pm)
+    for i, o in enumerate(outs):
+        lo = spans[i][0]
+        main.wait_stream(_side_stream(dense_pm.device, ("mb", i)))
+        for dst, src, w in ((R, o[0], 9), (t, o[1], 3), (sc, o[2], 1)):
+            src.record_stream(main)
+            _lib.call("sam6d_copy_f32", _p(src), _p(dst, lo * w), src.numel(), _s())
+    return R, t, sc
 
 
 def radius_normalize(pts, dense_po):
