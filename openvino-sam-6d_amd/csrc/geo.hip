@@ -611,7 +611,8 @@ extern "C" int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, c
 
 static int geo_check(int B, int n, int angle_k, int hidden) {
   SAM6D_REQUIRE(angle_k == 3 && hidden == 256, "geo_embedding: only angle_k=3, hidden_dim=256 (PEM/config/base.yaml:26-31)");
-  SAM6D_REQUIRE(B >= 0 && n >= 4 && n <= 256, "geo_embedding: need 4 <= n <= 256 (got %d)", n);
+  SAM6D_REQUIRE(B >= 0 && B <= 65535 && n >= 4 && n <= 256, "geo_embedding: need B <= 65535 and 4 <= n <= 256 (got B = %d, n = %d)",
+                B, n);
   return 0;
 }
 
