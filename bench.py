@@ -145,8 +145,9 @@ def main():
             ref_flop = clouds * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
             roofline = {"bound": "mfma",
                         "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16x3 split = 3 MFMA products per fp32 product), "
-                                  "one RPE layer over %d clouds per launch, %d launches per step on %d concurrent streams "
-                                  "(durations include the other stream's kernels)" % (clouds, 6 * mb, mb),
+                                  "with its outlier-pair kernel; one RPE layer over %d clouds per launch, %d launches per step%s"
+                                  % (clouds, 6 * mb, "" if mb == 1 else " on %d concurrent streams (durations include the other "
+                                     "streams' kernels)" % mb),
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": flop / 1e9,
