@@ -202,9 +202,11 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       auto consume = [&](int cb, int r) {  // max over the angular rows, 4 head dots of key row 4 kg + r
         const int b = cb & 1;
         const float g = __builtin_fmaxf(__builtin_fmaxf(acc[b][0][r], acc[b][1][r]), acc[b][2][r]);
-        const f2 gg = f2{g, g};
-        s01[r] = __builtin_elementwise_fma(gg, f2{qv[cb % 3].x, qv[cb % 3].y}, s01[r]);
-        s23[r] = __builtin_elementwise_fma(gg, f2{qv[cb % 3].z, qv[cb % 3].w}, s23[r]);
+        // four plain FMAs: v_pk_fma_f32 issues at half rate on gfx950 (no gain) and packed fp32 is avoided library-wide
+        s01[r].x = fmaf(g, qv[cb % 3].x, s01[r].x);
+        s01[r].y = fmaf(g, qv[cb % 3].y, s01[r].y);
+        s23[r].x = fmaf(g, qv[cb % 3].z, s23[r].x);
+        s23[r].y = fmaf(g, qv[cb % 3].w, s23[r].y);
       };
       load_w(0);
       load_w(1);

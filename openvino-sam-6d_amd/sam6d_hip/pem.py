@@ -646,12 +646,10 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
 
     cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 1 = off): the batch is cut into k slices whose coarse / fine stages run
-    on k HIP streams (one slice's latency-bound chains beside another's dense kernels, +2 % at k = 2).  FPS, gathers and the
-    geometric indices of every slice are computed first, serially, on the caller's stream: geo_index_kernel returns wrong
-    angular indices (in groups of 16 lanes) whenever a split-fp16 MFMA kernel of this library runs on the chip at the same
-    time -- found with scratch/dbg_pair2.py; exact-fp32 MFMA GEMMs, rocBLAS, LayerNorm, ball query and copies do not trigger
-    it, and no other stage is affected (scratch/dbg_pair.py, scratch/dbg_ov.py: 0 of 100 runs differ at k = 2 with the serial
-    prepare; 49 of 150 without it).  The same rule keeps the default pipeline safe: its side stream forks after the indices."""
+    on k HIP streams (one slice's latency-bound chains beside another's dense kernels, +2 % at k = 2, twice the host launch work).
+    FPS, gathers and the geometric indices of every slice are computed first, serially, on the caller's stream -- defence in
+    depth for the packed-fp32 / f16-MFMA hazard described in DESIGN "Concurrency caveat" (the library is built without packed
+    fp32 instructions since).  scratch/dbg_ov.py: 0 of 60 two-slice runs differ from the serial result."""
     B = dense_pm.shape[0]
     mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
     fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() == 1
@@ -659,8 +657,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
 
     def prepare(lo, hi):
         """FPS, gathers and the geometric indices of proposals [lo, hi): always on the caller's stream, never beside other
-        kernels (geo_index_kernel returns wrong angles when split-fp16 MFMA kernels run concurrently on the chip: see
-        DESIGN 6)."""
+        kernels (DESIGN "Concurrency caveat")."""
         b = hi - lo
         dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
         df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
