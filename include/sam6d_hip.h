@@ -84,6 +84,11 @@ int sam6d_get_matmul_mode(void);
 /* nn.LayerNorm(256) over `rows` rows (PEM/model/transformer.py:158,189,436,597).  eps as in torch (1e-5). */
 int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, float* y, long rows, long ldx, long ldy,
                        float eps, void* stream);
+/* attention.linear / output.squeeze + residual + LayerNorm of a transformer block in one launch
+ * (PEM/model/transformer.py:152-158, 184-199, 436-441, 597-603): Y (M,256) = LayerNorm(A (M,K) . W (256,K)^T + bias + residual)
+ * * gamma + beta, eps as nn.LayerNorm.  Split-precision mode only (rc < 0 in mode 0: use sam6d_gemm_nt + sam6d_layernorm256). */
+int sam6d_gemm_ln256(const float* A, const float* W, const float* bias, const float* residual, const float* gamma,
+                     const float* beta, float* Y, int M, int K, long lda, long ldw, long ldr, long ldy, float eps, void* stream);
 
 /* replaces GeometricStructureEmbedding.forward (PEM/model/transformer.py:343-363; indices :306-341; sinusoid :259-285).
  * points (B,n,3) (bg point already prepended) -> out (B,n,n,256).  Workspaces: knn_ws (B*n*3 + 1) i32 (the last int is

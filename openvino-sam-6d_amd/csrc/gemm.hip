@@ -447,6 +447,176 @@ extern "C" int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GEMM + bias + residual + LayerNorm in one kernel for the 256-wide projections that every transformer block ends with
+// (attention.linear -> +x -> norm, output.squeeze -> +y -> norm: PEM/model/transformer.py:152-199, 436-479, 597-622):
+//     Y[m, :] = LayerNorm(A[m, :] . W^T + bias + R[m, :]) * gamma + beta          N = 256 fixed
+// One workgroup owns 64 full rows (BN = 256: wave w has columns [64 w, 64 w + 64)), so the row statistics never leave the
+// chip: per-lane partial sums -> DPP / permlane reduction over the 32 column lanes -> 4 wave partials through LDS -> mean, then
+// the same for the centred squares (two-pass variance like layernorm256_kernel).  A is read once (the 128 x 128 tiling reads it
+// once per column tile) and the separate LayerNorm launch with its 2 x M x 1 KiB of traffic disappears.
+// Split-precision (fp16 x3) arithmetic as gemm_nt_h3_kernel; staging identical.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_ln_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* __restrict__ residual,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ Y, int M, int K, long lda, long ldw, long ldr,
+                                                         long ldy, float eps) {
+  constexpr int BM = 64, BN = 256, RA = 2, RB = 8;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * H_LD];
+  __shared__ float red[4][BM];
+  __shared__ float stat[BM];
+  _Float16* Ah = smem;
+  _Float16* Al = Ah + BM * H_LD;
+  _Float16* Bh = Al + BM * H_LD;
+  _Float16* Bl = Bh + BN * H_LD;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * BM, wn = wave * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sr = t >> 3, sk = (t & 7) * 4;
+  const float* ap[RA];
+  const float* bp[RB];
+#pragma unroll
+  for (int u = 0; u < RA; ++u) ap[u] = A + (size_t)min(m0 + sr + 32 * u, M - 1) * lda + sk;
+#pragma unroll
+  for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)(sr + 32 * u) * ldw + sk;
+  float4 va[RA], vb[RB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+  };
+  const int fr = lane & 31, fk = lane >> 5;
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += H_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RA; ++u) {
+      half4 hi, lo;
+      split4(va[u], hi, lo);
+      *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
+      *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      half4 hi, lo;
+      split4(vb[u], hi, lo);
+      *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
+      *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
+    }
+    __syncthreads();
+    if (k0 + H_BK < K) fetch(k0 + H_BK);
+#pragma unroll
+    for (int ks = 0; ks < H_BK; ks += 16) {
+      half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const half8*>(&Ah[(32 * i + fr) * H_LD + ks + 8 * fk]);
+        al[i] = *reinterpret_cast<const half8*>(&Al[(32 * i + fr) * H_LD + ks + 8 * fk]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+        bl[j] = *reinterpret_cast<const half8*>(&Bl[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: x = acc + bias + residual (kept in the accumulator registers)
+  float bv[2], gv[2], tv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = wn + 32 * j + fr;
+    bv[j] = bias ? bias[col] : 0.f;
+    gv[j] = gamma[col];
+    tv[j] = beta[col];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float rv[2][16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        rv[j][r] = (residual && row < M) ? residual[(size_t)row * ldr + wn + 32 * j + fr] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] + bv[j]) + rv[j][r];
+  }
+  // row sums over this wave's 64 columns: 2 per lane, then the 32 lanes that share fk (row16 all-reduce + the lane 16 away)
+  auto wave_rows = [&](auto f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = f(i, r);
+        p = row16_sum_dpp(p);
+        p += xor16_f32(p);
+        if (fr == 0) red[wave][32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk] = p;
+      }
+  };
+  wave_rows([&](int i, int r) { return acc[i][0][r] + acc[i][1][r]; });
+  __syncthreads();
+  if (t < BM) stat[t] = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) * (1.0f / 256.0f);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float mean = stat[32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk];
+      acc[i][0][r] -= mean;
+      acc[i][1][r] -= mean;
+    }
+  __syncthreads();  // every lane has read `stat` before it is rewritten with the variances
+  wave_rows([&](int i, int r) { return acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r]; });
+  __syncthreads();
+  if (t < BM) stat[t] = 1.0f / sqrtf(((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) * (1.0f / 256.0f) + eps);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      const int row = m0 + rl;
+      if (row < M) {
+        const float rstd = stat[rl];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) Y[(size_t)row * ldy + wn + 32 * j + fr] = acc[i][j][r] * rstd * gv[j] + tv[j];
+      }
+    }
+}
+
+extern "C" int sam6d_gemm_ln256(const float* A, const float* W, const float* bias, const float* residual, const float* gamma,
+                                const float* beta, float* Y, int M, int K, long lda, long ldw, long ldr, long ldy, float eps,
+                                void* stream) {
+  SAM6D_REQUIRE(A && W && gamma && beta && Y, "gemm_ln256: null pointer");
+  SAM6D_REQUIRE(M >= 0 && K >= 32 && (K % 32) == 0, "gemm_ln256: K must be a positive multiple of 32 (got %d)", K);
+  SAM6D_REQUIRE(lda >= K && ldw >= K && ldy >= 256 && (!residual || ldr >= 256), "gemm_ln256: leading dimension too small");
+  SAM6D_REQUIRE(((lda | ldw) & 3) == 0 && ((((size_t)A) | ((size_t)W)) & 15) == 0, "gemm_ln256: A and W rows must be 16-byte aligned");
+  SAM6D_REQUIRE(g_matmul_mode == 1, "gemm_ln256: split-precision mode only (use sam6d_gemm_nt + sam6d_layernorm256 in mode 0)");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(gemm_ln_h3_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, A, W, bias, residual, gamma,
+                     beta, Y, M, K, lda, ldw, ldr, ldy, eps);
+  SAM6D_LAUNCH_CHECK("gemm_ln256");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm over rows of C=256 (nn.LayerNorm, eps 1e-5; PEM/model/transformer.py:158,189,436,597): one wave per
 // row, 4 floats per lane, two-pass mean/variance in registers.  The residual add is fused into the producing GEMM.
 // ---------------------------------------------------------------------------------------------------------------

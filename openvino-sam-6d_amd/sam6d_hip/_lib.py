@@ -25,6 +25,7 @@ SIGNATURES = {
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_set_matmul_mode": [c_i],
     "sam6d_layernorm256": [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_f, c_p],
+    "sam6d_gemm_ln256": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_f, c_p],
     "sam6d_geo_embedding": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_geo_indices": [c_p, c_i, c_i, c_f, c_f, c_i, c_p, c_p, c_p],
     "sam6d_geo_embed": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p],

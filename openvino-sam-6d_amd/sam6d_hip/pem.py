@@ -187,9 +187,24 @@ def layernorm(x2d, gb, out=None):
 def _post_attention(hidden, x2d, L):
     """linear -> +residual -> LayerNorm -> AttentionOutput (expand, ReLU, squeeze, +residual, LayerNorm)
     (PEM/model/transformer.py:152-199)."""
+    # SAM6D_FUSED_LN=1: projection + residual + LayerNorm in one launch (sam6d_gemm_ln256).  Off by default: measured 1 % slower
+    # than the two launches (64-row tiles at 184 registers and 4-byte stores cost what the saved LayerNorm pass gives back).
+    if _lib.load().sam6d_get_matmul_mode() == 1 and os.environ.get("SAM6D_FUSED_LN", "0") == "1":
+        y = gemm_ln(hidden, L["lin"], x2d, L["n1"])
+        h = linear(y, L["exp"], act=1)
+        return gemm_ln(h, L["sq"], y, L["n2"])
     y = layernorm(linear(hidden, L["lin"], residual=x2d), L["n1"])
     h = linear(y, L["exp"], act=1)
     return layernorm(linear(h, L["sq"], residual=y), L["n2"])
+
+
+def gemm_ln(x, lin, residual, norm, eps=1e-5):
+    """LayerNorm(x @ lin.w^T + lin.b + residual) for 256 output channels (sam6d_gemm_ln256)."""
+    M, K = x.shape
+    out = _empty((M, C), x)
+    _lib.call("sam6d_gemm_ln256", _p(x), _p(lin.w), _p(lin.b), _p(residual), _p(norm[0]), _p(norm[1]), _p(out), M, K, K, K, C, C,
+              float(eps), _s())
+    return out
 
 
 # optional profiling hook: bench.py sets PROFILE = {} and reads back lists of (start, end) torch.cuda.Event pairs per

@@ -543,6 +543,24 @@ def test_pem_match_repeatable_with_side_stream(dev, W):
             assert torch.equal(a, b), "run %d with the side stream: %s differs by %.3e" % (rep, what, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize("M,K", [(1, 256), (197, 256), (6304, 512), (65, 32), (4099, 256)])
+def test_gemm_ln256_matches_gemm_then_layernorm(dev, M, K):
+    """sam6d_gemm_ln256 (projection + residual + LayerNorm fused) against the two-launch form and torch fp64."""
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("fused projection + LayerNorm exists in the split-precision mode only")
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g); w = torch.randn(256, K, generator=g) / math.sqrt(K); b = torch.randn(256, generator=g)
+    res = torch.randn(M, 256, generator=g); gam = torch.rand(256, generator=g) + 0.5; bet = torch.randn(256, generator=g)
+    lin = pem.Linear(w.to(dev), b.to(dev))
+    got = pem.gemm_ln(x.to(dev), lin, res.to(dev), (gam.to(dev), bet.to(dev))).cpu()
+    two = pem.layernorm(pem.linear(x.to(dev), lin, residual=res.to(dev)), (gam.to(dev), bet.to(dev))).cpu()
+    want = torch.nn.functional.layer_norm(x.double() @ w.double().t() + b.double() + res.double(), (256,), gam.double(), bet.double(), 1e-5)
+    assert torch.isfinite(got).all()
+    _close(got, two, 5e-6, "fused vs gemm + layernorm")
+    _close(got, want.float(), 2e-5, "fused vs torch fp64")
+
+
 def test_config5_shape_4096_points(dev, W, sd):
     """BASELINE config 5's geometry (fine_npoint = 4096): the whole path at N = 4096 dense points, B = 1, against the CPU
     oracle (fp32; the config's fp16 attention variant is a later round)."""
