@@ -389,8 +389,7 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
 
 
 // pos[pair] = -1 when all four indices of the pair lie in [0, xmax] (Chebyshev range), else its slot in list[1..]; list[0] = count
-// zeroes the list counter.  A kernel, not hipMemsetAsync: the fill must be ordered with the atomics of the next kernel like any
-// other launch on the stream
+// zeroes the list counter (a kernel rather than hipMemsetAsync: one launch path for everything on the stream)
 __global__ void geo_list_reset_kernel(int* __restrict__ list) { list[0] = 0; }
 
 __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax,
@@ -402,9 +401,7 @@ __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restr
   int p = -1;
   if (!ok) {
     p = atomicAdd(list, 1);
-    // slots are handed out across the whole grid, so neighbouring entries of one cache line are written from different
-    // XCDs: store them at agent scope (memory-side, like the atomic) instead of leaving partial dirty lines in eight L2s
-    __hip_atomic_store(&list[1 + p], (int)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    list[1 + p] = (int)e;
   }
   pos[e] = p;
 }
