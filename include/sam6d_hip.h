@@ -45,6 +45,11 @@ int sam6d_gather_points(const float* points, const int* idx, int B, int C, int N
  * every slot written (empty ball -> zeros, like the reference's zero-initialised output). */
 int sam6d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample, int* idx,
                      void* stream);
+/* sam6d_ball_query for two radii over the same (queries, cloud) in one pass -- PositionalEncoding queries r1 = 0.1 / 32 samples
+ * and r2 = 0.2 / 64 samples around the same points (PEM/model/fine_point_matching.py:108-131, EXT/src/ball_query.cpp:16-62);
+ * idx1 (B,M,nsample1), idx2 (B,M,nsample2), each identical to the single-radius call. */
+int sam6d_ball_query2(const float* new_xyz, const float* xyz, int B, int N, int M, float radius1, int nsample1, int* idx1,
+                      float radius2, int nsample2, int* idx2, void* stream);
 
 /* replaces `at::Tensor group_points(at::Tensor points, at::Tensor idx)` (EXT/src/group_points.cpp:79-108; loop :20-45).
  * points (B,C,N) f32, idx (B,M,S) i32 -> out (B,C,M,S) f32. */

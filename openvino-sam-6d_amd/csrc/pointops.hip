@@ -278,6 +278,96 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
   }
 }
 
+// Two radii in one pass over the candidates (PositionalEncoding queries the same cloud with r1 < r2: fine_point_matching.py
+// :108-131): the distance of a (query, candidate) pair is computed once, each radius keeps its own hit counter and index list.
+// Same per-radius semantics as ball_query_kernel (index order, first hit pre-fills, empty ball -> zeros).
+__global__ __launch_bounds__(256) void ball_query2_kernel(const float* __restrict__ new_xyz, const float* __restrict__ xyz, int N,
+                                                          int M, float r2a, int nsa, int* __restrict__ idxa, float r2b, int nsb,
+                                                          int* __restrict__ idxb) {
+  __shared__ float sp[BQ_CH * 3];
+  __shared__ int s_cnt[2][BQ_QPB];
+  __shared__ int s_first[2][BQ_QPB];
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * BQ_QPB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cx = xyz + (size_t)b * N * 3;
+  const float* cq = new_xyz + (size_t)b * M * 3;
+  int* cia = idxa + (size_t)b * M * nsa;
+  int* cib = idxb + (size_t)b * M * nsb;
+  if (threadIdx.x < BQ_QPB) {
+    s_cnt[0][threadIdx.x] = s_cnt[1][threadIdx.x] = 0;
+    s_first[0][threadIdx.x] = s_first[1][threadIdx.x] = 0;
+  }
+  for (int base = 0; base < N; base += BQ_CH) {
+    const int cn = min(BQ_CH, N - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cn * 3; i += 256) sp[i] = cx[(size_t)base * 3 + i];
+    __syncthreads();
+    for (int ql = wave; ql < BQ_QPB; ql += 4) {
+      const int q = q0 + ql;
+      if (q >= M) break;
+      int ca = s_cnt[0][ql], cb = s_cnt[1][ql];
+      if (ca >= nsa && cb >= nsb) continue;
+      const float qx = cq[q * 3 + 0], qy = cq[q * 3 + 1], qz = cq[q * 3 + 2];
+      int fa = s_first[0][ql], fb = s_first[1][ql];
+      for (int k0 = 0; k0 < cn && (ca < nsa || cb < nsb); k0 += 64) {
+        const int k = k0 + lane;
+        float d2 = INFINITY;
+        if (k < cn) {
+          const float x = sp[k * 3 + 0], y = sp[k * 3 + 1], z = sp[k * 3 + 2];
+          d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+        }
+        if (ca < nsa) {
+          const bool hit = d2 < r2a;
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            if (ca == 0) fa = base + k0 + (__ffsll((long long)mask) - 1);
+            const int pos = ca + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < nsa) cia[(size_t)q * nsa + pos] = base + k;
+            ca += __popcll(mask);
+          }
+        }
+        if (cb < nsb) {
+          const bool hit = d2 < r2b;
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            if (cb == 0) fb = base + k0 + (__ffsll((long long)mask) - 1);
+            const int pos = cb + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && pos < nsb) cib[(size_t)q * nsb + pos] = base + k;
+            cb += __popcll(mask);
+          }
+        }
+      }
+      if (lane == 0) {
+        s_cnt[0][ql] = ca;
+        s_cnt[1][ql] = cb;
+        s_first[0][ql] = fa;
+        s_first[1][ql] = fb;
+      }
+    }
+  }
+  __syncthreads();
+  for (int ql = wave; ql < BQ_QPB; ql += 4) {  // tail fill: slots [cnt, nsample) hold the first hit (or 0 when the ball is empty)
+    const int q = q0 + ql;
+    if (q >= M) break;
+    const int ca = min(s_cnt[0][ql], nsa), cb = min(s_cnt[1][ql], nsb), fa = s_first[0][ql], fb = s_first[1][ql];
+    for (int l = ca + lane; l < nsa; l += 64) cia[(size_t)q * nsa + l] = fa;
+    for (int l = cb + lane; l < nsb; l += 64) cib[(size_t)q * nsb + l] = fb;
+  }
+}
+
+extern "C" int sam6d_ball_query2(const float* new_xyz, const float* xyz, int B, int N, int M, float radius1, int nsample1, int* idx1,
+                                 float radius2, int nsample2, int* idx2, void* stream) {
+  SAM6D_REQUIRE(new_xyz && xyz && idx1 && idx2, "ball_query2: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample1 > 0 && nsample2 > 0, "ball_query2: bad sizes");
+  SAM6D_REQUIRE(B <= 65535, "ball_query2: B must be <= 65535");
+  if (B == 0 || M == 0) return 0;
+  dim3 grid(cdiv(M, BQ_QPB), B);
+  hipLaunchKernelGGL(ball_query2_kernel, grid, dim3(256), 0, (hipStream_t)stream, new_xyz, xyz, N, M, radius1 * radius1, nsample1,
+                     idx1, radius2 * radius2, nsample2, idx2);
+  SAM6D_LAUNCH_CHECK("ball_query2");
+}
+
 extern "C" int sam6d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
                                 int* idx, void* stream) {
   SAM6D_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");

@@ -20,6 +20,7 @@ SIGNATURES = {
     "sam6d_furthest_point_sampling": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_gather_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_ball_query": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
+    "sam6d_ball_query2": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_f, c_i, c_p, c_p],
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],

@@ -476,9 +476,10 @@ def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32
     feat = _empty((Bp * N, 2 * 128), pts)
     q = _empty((Bp, N, 3), pts)  # new_xyz = pts + 1e-8 (fine_point_matching.py:117)
     _lib.call("sam6d_add_scalar", _p(pts), 0.00000001, Bp * N * 3, _p(q), _s())
-    for k, (r, ns) in enumerate(((r1, ns1), (r2, ns2))):
-        idx = _empty((Bp, N, ns), pts, torch.int32)
-        _lib.call("sam6d_ball_query", _p(q), _p(pts), Bp, N, N, float(r), ns, _p(idx), _s())
+    idx12 = (_empty((Bp, N, ns1), pts, torch.int32), _empty((Bp, N, ns2), pts, torch.int32))
+    _lib.call("sam6d_ball_query2", _p(q), _p(pts), Bp, N, N, float(r1), ns1, _p(idx12[0]), float(r2), ns2, _p(idx12[1]), _s())
+    for k, ns in enumerate((ns1, ns2)):
+        idx = idx12[k]
         L = W.pe["mlp"][k]
         _lib.call("sam6d_pe_mlp_max", _p(pts), _p(idx), Bp, N, ns, _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
                   _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),

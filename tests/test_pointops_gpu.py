@@ -143,3 +143,24 @@ def test_error_contract(dev, ext):
         ext.gather_points(x, torch.zeros(1, 4, dtype=torch.int64, device=dev))  # idx must be int32
     with pytest.raises(NotImplementedError):
         ext.three_nn(x, x)
+
+
+@pytest.mark.parametrize("B,N,M,r1,ns1,r2,ns2", [(2, 2048, 2048, 0.1, 32, 0.2, 64), (1, 5000, 300, 0.05, 16, 0.4, 64), (3, 100, 100, 0.3, 8, 0.01, 4)])
+def test_ball_query2_equals_two_single_queries(dev, B, N, M, r1, ns1, r2, ns2):
+    """The two-radius pass used by the positional encoding returns exactly what two single-radius calls return."""
+    from sam6d_hip import _lib
+    g = torch.Generator().manual_seed(N + M)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    new = (xyz[:, :M] + 1e-8).contiguous() if M <= N else torch.rand(B, M, 3, generator=g).to(dev)
+    new[:, 0] = 5.0  # an empty ball
+    single = []
+    for r, ns in ((r1, ns1), (r2, ns2)):
+        idx = torch.full((B, M, ns), -7, dtype=torch.int32, device=dev)
+        _lib.call("sam6d_ball_query", new.data_ptr(), xyz.data_ptr(), B, N, M, float(r), ns, idx.data_ptr(), None)
+        single.append(idx)
+    i1 = torch.full((B, M, ns1), -7, dtype=torch.int32, device=dev)
+    i2 = torch.full((B, M, ns2), -7, dtype=torch.int32, device=dev)
+    _lib.call("sam6d_ball_query2", new.data_ptr(), xyz.data_ptr(), B, N, M, float(r1), ns1, i1.data_ptr(), float(r2), ns2,
+              i2.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, single[0]) and torch.equal(i2, single[1])
