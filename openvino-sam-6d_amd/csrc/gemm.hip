@@ -409,7 +409,8 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   if (M == 0 || N == 0 || batch == 0) return 0;
   const int nz = batch * b2.n2;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * nz;
-  const bool big = blocks128 >= 1024;  // >= 4 workgroups per CU: big tiles
+  // big tiles when they fill the chip (>= 4 workgroups per CU) and do not mostly pad (M = 197 would waste 42 % of a 2 x 128 split)
+  const bool big = blocks128 >= 1024 && (M > 256 || M % 128 == 0);
   const int tm = cdiv(M, big ? 128 : 64), tn = cdiv(N, big ? 128 : 64);
   // all tiles on x (2^31 limit) in the XCD-aware order the kernels decode; groups of 8 row tiles are padded
   const long tiles = (tn <= 8 && tm >= 32) ? (long)cdiv(tm, 8) * 8 * tn : (long)tm * tn;
