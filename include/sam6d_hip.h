@@ -279,6 +279,21 @@ int sam6d_take_rows(const void* src, const long long* idx, long n_src, int M, lo
 size_t sam6d_nms_workspace_bytes(int N);
 int sam6d_nms(const float* boxes, const float* scores, const long long* group, int N, float thresh, long long* keep_idx,
               int* count, void* ws, size_t ws_bytes, void* stream);
+/* Proposal geometry of get_test_data (PEM/run_inference_custom_pytorch.py:316-355) on resident data; masks (N,H,W) u8, depth (H,W)
+ * f32 metres.
+ * sam6d_mask_bbox: bbox (N,4) i32 = get_bbox((mask > 0) & (depth > 0)) (PEM/utils/data_utils.py:125-160), count (N) valid pixels.
+ * sam6d_crop_masked_points: the valid pixels of each crop in row-major order: choose (N,cap) i32 flat crop indices, cloud (N,cap,3)
+ *   back-projected points (get_point_cloud_from_depth, data_utils.py:92-110), n_valid (N) (:326-330).
+ * sam6d_radius_filter: in-place removal of the points farther than radius * 1.2 from their mean (:331-337); n_keep (N), center (N,3).
+ * sam6d_choose_points: pts (N,ns,3) = cloud[sel], rgb_choose (N,ns) i64 = get_resize_rgb_choose(choose[sel], bbox, img_size)
+ *   (data_utils.py:113-123); sel (N,ns) i32 is the caller's np.random.choice (:339-345). */
+int sam6d_mask_bbox(const unsigned char* masks, const float* depth, int N, int H, int W, int* bbox, int* count, void* stream);
+int sam6d_crop_masked_points(const unsigned char* masks, const float* depth, int N, int H, int W, const int* bbox, float fx, float fy,
+                             float cx, float cy, int cap, int* choose, float* cloud, int* n_valid, void* stream);
+int sam6d_radius_filter(int N, int cap, const int* n_valid, float radius, int* choose, float* cloud, int* n_keep, float* center,
+                        void* stream);
+int sam6d_choose_points(int N, int cap, const int* choose, const float* cloud, const int* bbox, const int* sel, int ns, int img_size,
+                        float* pts, long long* rgb_choose, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,10 @@ SIGNATURES = {
     "sam6d_take_rows": [c_p, c_p, c_l, c_i, c_l, c_p, c_p],
     "sam6d_nms_workspace_bytes": [c_i],
     "sam6d_nms": [c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "sam6d_mask_bbox": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_crop_masked_points": [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p, c_p, c_p, c_p],
+    "sam6d_radius_filter": [c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
+    "sam6d_choose_points": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
 }
 

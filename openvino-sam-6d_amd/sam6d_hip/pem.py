@@ -771,6 +771,44 @@ def depth_to_cloud(depth, K, bbox=None):
     return out
 
 
+def proposal_geometry(masks, depth, K, radius, cap=None):
+    """The per-proposal geometry of get_test_data before the random choice (PEM/run_inference_custom_pytorch.py:316-337):
+    masks (N,H,W) uint8/bool, depth (H,W) f32 metres, K 3x3, radius = max CAD point norm.
+    -> dict(bbox (N,4) i32, count (N), choose (N,cap) i32, cloud (N,cap,3), n_keep (N), center (N,3)); proposals with count <= 32
+    or n_keep < 4 are the ones the reference skips (:320-324, :334-335) -- the caller filters on those two vectors."""
+    from .ops import _chk
+    masks = masks.to(torch.uint8).contiguous()
+    depth = depth.contiguous()
+    _chk(masks, "masks", torch.uint8, 3)
+    _chk(depth, "depth", torch.float32, 2)
+    N, H, Wd = masks.shape
+    bbox = _empty((N, 4), depth, torch.int32)
+    count = _empty((N,), depth, torch.int32)
+    _lib.call("sam6d_mask_bbox", _p(masks), _p(depth), N, H, Wd, _p(bbox), _p(count), _s())
+    cap = int(cap) if cap is not None else min(H, Wd) ** 2  # the crop is a square of side <= min(H, W)
+    choose = _empty((N, cap), depth, torch.int32)
+    cloud = _empty((N, cap, 3), depth)
+    n_valid = _empty((N,), depth, torch.int32)
+    _lib.call("sam6d_crop_masked_points", _p(masks), _p(depth), N, H, Wd, _p(bbox), float(K[0][0]), float(K[1][1]), float(K[0][2]),
+              float(K[1][2]), cap, _p(choose), _p(cloud), _p(n_valid), _s())
+    n_keep = _empty((N,), depth, torch.int32)
+    center = _empty((N, 3), depth)
+    _lib.call("sam6d_radius_filter", N, cap, _p(n_valid), float(radius), _p(choose), _p(cloud), _p(n_keep), _p(center), _s())
+    return dict(bbox=bbox, count=count, choose=choose, cloud=cloud, n_valid=n_valid, n_keep=n_keep, center=center, cap=cap)
+
+
+def proposal_choose(geom, sel, img_size=224):
+    """pts (N,ns,3) and rgb_choose (N,ns) i64 for the caller's random choice sel (N,ns) into the kept points of each proposal
+    (PEM/run_inference_custom_pytorch.py:339-355, get_resize_rgb_choose PEM/utils/data_utils.py:113-123)."""
+    sel = sel.to(torch.int32).contiguous()
+    N, ns = sel.shape
+    pts = _empty((N, ns, 3), geom["cloud"])
+    rc = _empty((N, ns), geom["cloud"], torch.int64)
+    _lib.call("sam6d_choose_points", N, geom["cap"], _p(geom["choose"]), _p(geom["cloud"]), _p(geom["bbox"]), _p(sel), ns, int(img_size),
+              _p(pts), _p(rc), _s())
+    return pts, rc
+
+
 def _cat0(a, b):
     """stack two (B,N,K) tensors along the batch -- a device copy, no arithmetic"""
     a = a.contiguous()

@@ -123,6 +123,66 @@ class RandPatch:
 
 
 # ------------------------------------------------------------------------------------------------- fixtures
+def fx_test_data(ext, mods):
+    """the proposal geometry of get_test_data (PEM/run_inference_custom_pytorch.py:316-355).  The function itself
+    reads files and needs cocomask / trimesh / cv2; its helpers get_bbox, get_resize_rgb_choose and get_point_cloud_from_depth
+    (PEM/utils/data_utils.py) are called from the reference here and composed exactly as lines 316-355 compose them."""
+    for name in ("imageio", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    du = importlib.import_module("data_utils")
+    g = np.random.default_rng(11)
+    H, Wd = 120, 160
+    yy, xx = np.mgrid[0:H, 0:Wd]
+    depth = (0.9 + 0.002 * xx + 0.001 * yy + 0.01 * g.standard_normal((H, Wd))).astype(np.float32)
+    depth[g.random((H, Wd)) < 0.08] = 0
+    depth[40:60, 60:64] = 3.5  # a strip far behind the object: removed by the radius filter
+    K = np.array([[200.0, 0, 80.0], [0, 200.0, 60.0], [0, 0, 1]], np.float32)
+    radius = np.float32(0.16)
+    masks = np.zeros((7, H, Wd), np.uint8)
+    masks[0] = ((xx - 70) ** 2 + (yy - 50) ** 2 < 24 ** 2) & (g.random((H, Wd)) > 0.15)  # blob in the middle
+    masks[1, 0:30, 0:12] = 1            # tall box in the corner: the square crop is shifted back into the image
+    masks[2, 100:120, 130:160] = 1      # bottom-right corner
+    masks[3, 55:60, 10:150] = 1         # wide strip: side limited by min(H, W)
+    masks[4, 10:15, 10:15] = 1          # 25 px: skipped (<= 32 valid pixels)
+    masks[5] = (np.abs(xx - 100) + np.abs(yy - 70) < 21)  # diamond, odd tight box
+    masks[6, 20:50, 20:50] = (g.random((30, 30)) > 0.5)
+    whole = du.get_point_cloud_from_depth(depth, K)
+    ns, img_size = 64, 224
+    out = {}
+    keep_ids, sels = [], []
+    for i in range(masks.shape[0]):
+        mask = np.logical_and(masks[i] > 0, depth > 0)
+        ref = None
+        if np.sum(mask) > 32:
+            bbox = du.get_bbox(mask)
+            y1, y2, x1, x2 = bbox
+            m = mask[y1:y2, x1:x2]
+            choose = m.astype(np.float32).flatten().nonzero()[0]
+            cloud = whole.copy()[y1:y2, x1:x2, :].reshape(-1, 3)[choose, :]
+            center = np.mean(cloud, axis=0)
+            tmp = cloud - center[None, :]
+            flag = np.linalg.norm(tmp, axis=1) < np.float32(np.float64(radius) * 1.2)  # `radius * 1.2` under numpy 1.26
+            if np.sum(flag) >= 4:
+                choose, cloud = choose[flag], cloud[flag]
+                sel = g.integers(0, len(choose), ns)
+                rc = du.get_resize_rgb_choose(choose[sel], [y1, y2, x1, x2], img_size)
+                ref = dict(bbox=[int(v) for v in bbox], n_keep=len(choose), center=center, pts=cloud[sel], rgb_choose=rc, sel=sel,
+                           choose_sha=sha(torch.from_numpy(choose.astype(np.int32))), cloud_sha=sha(torch.from_numpy(cloud.copy())))
+        o = O.proposal_geometry(masks[i], depth, K, radius)
+        assert (o is None) == (ref is None), "oracle / reference disagree on skipping proposal %d" % i
+        if ref is None:
+            continue
+        assert o["bbox"] == ref["bbox"] and np.array_equal(o["center"], ref["center"]) and len(o["choose"]) == ref["n_keep"]
+        assert np.array_equal(o["cloud"][ref["sel"]], ref["pts"])
+        assert np.array_equal(O.get_resize_rgb_choose(o["choose"][ref["sel"]], o["bbox"], img_size), ref["rgb_choose"])
+        keep_ids.append(i)
+        for k, v in ref.items():
+            out["p%d_%s" % (i, k)] = np.asarray(v) if not isinstance(v, str) else v
+    save("test_data", depth=depth, masks=masks, K=K, radius=radius, ns=np.int32(ns), img_size=np.int32(img_size),
+         kept=np.array(keep_ids, np.int32), **out)
+
+
 def fx_depth_cloud(ext, mods):
     """get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) run from the reference itself (empty
     stub modules for the absent imageio / cv2, which this function does not touch).  K is handed over as float32 so that the
@@ -571,7 +631,7 @@ def fx_ism():
 
 
 ALL = ["pointops", "pairwise", "geo", "transformer", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
-       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "ism"]
+       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "ism"]
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

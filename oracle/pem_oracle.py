@@ -388,6 +388,64 @@ def depth_to_cloud(depth, K, bbox=None):
     return np.stack([pt0, pt1, pt2]).transpose((1, 2, 0))
 
 
+def get_bbox(label):
+    """PEM/utils/data_utils.py:125-160."""
+    import numpy as np
+    H, Wd = label.shape
+    rows = np.any(label, axis=1)
+    cols = np.any(label, axis=0)
+    rmin, rmax = np.where(rows)[0][[0, -1]]
+    cmin, cmax = np.where(cols)[0][[0, -1]]
+    rmax += 1
+    cmax += 1
+    b = min(max(rmax - rmin, cmax - cmin), min(H, Wd))
+    center = [int((rmin + rmax) / 2), int((cmin + cmax) / 2)]
+    rmin, rmax = center[0] - int(b / 2), center[0] + int(b / 2)
+    cmin, cmax = center[1] - int(b / 2), center[1] + int(b / 2)
+    if rmin < 0:
+        rmax, rmin = rmax - rmin, 0
+    if cmin < 0:
+        cmax, cmin = cmax - cmin, 0
+    if rmax > H:
+        rmin, rmax = rmin - (rmax - H), H
+    if cmax > Wd:
+        cmin, cmax = cmin - (cmax - Wd), Wd
+    return [int(rmin), int(rmax), int(cmin), int(cmax)]
+
+
+def get_resize_rgb_choose(choose, bbox, img_size):
+    """PEM/utils/data_utils.py:113-123."""
+    import numpy as np
+    rmin, rmax, cmin, cmax = bbox
+    crop_h, crop_w = rmax - rmin, cmax - cmin
+    ratio_h, ratio_w = img_size / crop_h, img_size / crop_w
+    row_idx, col_idx = choose // crop_w, choose % crop_w
+    return (np.floor(row_idx * ratio_h) * img_size + np.floor(col_idx * ratio_w)).astype(np.int64)
+
+
+def proposal_geometry(mask, depth, K, radius):
+    """One proposal of get_test_data up to the radius filter (PEM/run_inference_custom_pytorch.py:316-337).  `radius * 1.2` is
+    evaluated as under numpy 1.26, the version the reference pins: np.float32 scalar * Python float = float64, compared with the
+    float32 norms at its float32 value.  Returns None where the reference `continue`s."""
+    import numpy as np
+    whole_pts = depth_to_cloud(depth, K)
+    mask = np.logical_and(mask > 0, depth > 0)
+    if np.sum(mask) <= 32:
+        return None
+    bbox = get_bbox(mask)
+    y1, y2, x1, x2 = bbox
+    m = mask[y1:y2, x1:x2]
+    choose = m.astype(np.float32).flatten().nonzero()[0]
+    cloud = whole_pts.copy()[y1:y2, x1:x2, :].reshape(-1, 3)[choose, :]
+    center = np.mean(cloud, axis=0)
+    tmp = cloud - center[None, :]
+    thr = np.float32(np.float64(np.float32(radius)) * 1.2)
+    flag = np.linalg.norm(tmp, axis=1) < thr
+    if np.sum(flag) < 4:
+        return None
+    return dict(bbox=bbox, count=int(np.sum(mask)), choose=choose[flag], cloud=cloud[flag], center=center)
+
+
 # -------------------------------------------------------------------------------- modules (a14)
 def coarse_point_matching(p1, f1, g1, p2, f2, g2, radius, model, sd, rand, cfg=DEFAULT_CFG, faithful=False,
                           return_aux=False, p="coarse_point_matching"):

@@ -190,3 +190,61 @@ def test_take_rows_dtypes(dev):
         m = torch.tensor([1, 0, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
         assert torch.equal(ism.take_rows(t.to(dev), m.to(dev)).cpu(), t[m])
     assert ism.take_rows(torch.rand(4, 2).to(dev), torch.zeros(0, dtype=torch.int64).to(dev)).shape == (0, 2)
+
+
+# ---------------------------------------------------------------------------- get_test_data geometry (row f2)
+def test_proposal_geometry_golden_bit_exact(dev):
+    """mask & depth -> crop box -> ordered masked pixels -> radius filter -> chosen points and resized-crop indices, against the
+    values composed from the reference's own helpers (tests/golden/test_data.npz)."""
+    import hashlib
+    from tests._util import golden
+    from sam6d_hip import pem
+    g = golden("test_data")
+    masks = torch.from_numpy(g["masks"]).to(dev)
+    depth = torch.from_numpy(g["depth"]).to(dev)
+    geom = pem.proposal_geometry(masks, depth, g["K"], float(g["radius"]))
+    kept = [int(i) for i in g["kept"]]
+    count = geom["count"].cpu().numpy(); n_keep = geom["n_keep"].cpu().numpy()
+    ours = [i for i in range(masks.shape[0]) if count[i] > 32 and n_keep[i] >= 4]
+    assert ours == kept, (ours, kept)
+    ns = int(g["ns"])
+    sel = torch.zeros(masks.shape[0], ns, dtype=torch.int32)
+    for i in kept:
+        sel[i] = torch.from_numpy(g["p%d_sel" % i].astype(np.int32))
+    pts, rc = pem.proposal_choose(geom, sel.to(dev), int(g["img_size"]))
+    for i in kept:
+        assert geom["bbox"][i].cpu().tolist() == [int(v) for v in g["p%d_bbox" % i]]
+        k = int(g["p%d_n_keep" % i])
+        assert int(n_keep[i]) == k
+        assert np.array_equal(geom["center"][i].cpu().numpy(), g["p%d_center" % i])
+        ch = np.ascontiguousarray(geom["choose"][i, :k].cpu().numpy())
+        cl = np.ascontiguousarray(geom["cloud"][i, :k].cpu().numpy())
+        assert hashlib.sha256(ch.tobytes()).hexdigest() == str(g["p%d_choose_sha" % i])
+        assert hashlib.sha256(cl.tobytes()).hexdigest() == str(g["p%d_cloud_sha" % i])
+        assert np.array_equal(pts[i].cpu().numpy(), g["p%d_pts" % i])
+        assert np.array_equal(rc[i].cpu().numpy(), g["p%d_rgb_choose" % i])
+
+
+def test_proposal_geometry_random_masks_vs_oracle(dev):
+    from oracle import pem_oracle as O
+    from sam6d_hip import pem
+    g = np.random.default_rng(3)
+    H, Wd, N = 96, 128, 12
+    yy, xx = np.mgrid[0:H, 0:Wd]
+    depth = (0.5 + 0.004 * xx + 0.3 * g.random((H, Wd))).astype(np.float32)
+    depth[g.random((H, Wd)) < 0.1] = 0
+    masks = np.zeros((N, H, Wd), np.uint8)
+    for i in range(N):
+        cy, cx, r = g.integers(0, H), g.integers(0, Wd), g.integers(3, 40)
+        masks[i] = (((xx - cx) ** 2 + (yy - cy) ** 2) < r * r) & (g.random((H, Wd)) > 0.2)
+    K = np.array([[150.0, 0, 64.0], [0, 150.0, 48.0], [0, 0, 1]], np.float32)
+    geom = pem.proposal_geometry(torch.from_numpy(masks).to(dev), torch.from_numpy(depth).to(dev), K, 0.11)
+    for i in range(N):
+        o = O.proposal_geometry(masks[i], depth, K, np.float32(0.11))
+        cnt, nk = int(geom["count"][i]), int(geom["n_keep"][i])
+        assert (o is None) == (cnt <= 32 or nk < 4)
+        if o is None:
+            continue
+        assert geom["bbox"][i].cpu().tolist() == o["bbox"] and nk == len(o["choose"])
+        assert np.array_equal(geom["choose"][i, :nk].cpu().numpy(), o["choose"].astype(np.int32))
+        assert np.array_equal(geom["cloud"][i, :nk].cpu().numpy(), o["cloud"])

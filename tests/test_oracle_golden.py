@@ -308,3 +308,23 @@ def test_small_detection_keep_oracle():
     assert keep.tolist() == [True, True, True]
     keep = IO.small_detection_keep(boxes, masks, 0.1, 5e-3)  # box area > 25 px, mask area > 12.5 px
     assert keep.tolist() == [True, False, False]
+
+
+def test_test_data_geometry_matches_reference_capture():
+    """get_test_data's per-proposal geometry (PEM/run_inference_custom_pytorch.py:316-355) composed from the reference's own
+    get_bbox / get_point_cloud_from_depth / get_resize_rgb_choose (oracle/gen_golden.py::fx_test_data)."""
+    g = golden("test_data")
+    kept = set(int(i) for i in g["kept"])
+    for i in range(g["masks"].shape[0]):
+        o = O.proposal_geometry(g["masks"][i], g["depth"], g["K"], g["radius"])
+        assert (o is not None) == (i in kept)
+        if o is None:
+            continue
+        assert o["bbox"] == [int(v) for v in g["p%d_bbox" % i]]
+        assert len(o["choose"]) == int(g["p%d_n_keep" % i])
+        assert np.array_equal(o["center"], g["p%d_center" % i])
+        assert _sha(torch.from_numpy(o["choose"].astype(np.int32))) == str(g["p%d_choose_sha" % i])
+        assert _sha(torch.from_numpy(np.ascontiguousarray(o["cloud"]))) == str(g["p%d_cloud_sha" % i])
+        sel = g["p%d_sel" % i]
+        assert np.array_equal(o["cloud"][sel], g["p%d_pts" % i])
+        assert np.array_equal(O.get_resize_rgb_choose(o["choose"][sel], o["bbox"], int(g["img_size"])), g["p%d_rgb_choose" % i])
