@@ -92,3 +92,49 @@ def test_model_utils_functions(dev):
     gen = torch.Generator().manual_seed(int(gs["seed"]))
     a = torch.randn(2, 197, 256, generator=gen); b = torch.randn(2, 197, 256, generator=gen)
     _close(MU.compute_feature_similarity(a.to(dev), b.to(dev), "cosine", 0.1, True), gs["out"], 2e-5, "similarity")
+
+
+def test_net_forward_six_tensor_signature(net, dev):
+    """The reference's call site (PEM/run_inference_custom_pytorch.py:447-454): model(pts, rgb, rgb_choose, model, dense_po, dense_fo)
+    -> (pred_R, pred_t, pred_pose_score).  The ViT runs as plain PyTorch (random weights, out of scope); everything after it on the
+    HIP path.  Checked: shapes, proper rotations, and that forward == match on the features the encoder produced."""
+    g = torch.Generator().manual_seed(4)
+    B = 2
+    pts = ((torch.rand(B, 2048, 3, generator=g) - 0.5) * 0.2 + torch.tensor([0.0, 0.0, 0.8])).to(dev)
+    rgb = torch.rand(B, 3, 224, 224, generator=g).to(dev)
+    rgb_choose = torch.randint(0, 224 * 224, (B, 2048), generator=g).to(dev)
+    model = ((torch.rand(B, 1024, 3, generator=g) - 0.5) * 0.2).to(dev)
+    dense_po = ((torch.rand(B, 2048, 3, generator=g) - 0.5) * 0.2).to(dev)
+    dense_fo = torch.randn(B, 2048, 256, generator=g).to(dev)
+    rand = torch.rand(B, 18000, generator=g).to(dev)
+    net.coarse_point_matching.hypothesis_rand = rand
+    try:
+        with torch.no_grad():
+            R, t, s = net(pts, rgb, rgb_choose, model, dense_po, dense_fo)
+            pm, fm, po, fo, radius = net.feature_extraction(pts, rgb, rgb_choose, dense_po, dense_fo)
+            R2, t2, s2 = net.match(pm, fm, po, fo, radius, model)
+    finally:
+        net.coarse_point_matching.hypothesis_rand = None
+    assert R.shape == (B, 3, 3) and t.shape == (B, 3) and s.shape == (B,)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(s).all()
+    eye = torch.eye(3, device=dev).expand(B, 3, 3)
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5 and float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+    assert torch.equal(R, R2) and torch.equal(t, t2) and torch.equal(s, s2)
+    want_r = torch.norm(dense_po.cpu(), dim=2).max(1)[0]  # the torch-CPU recipe the reference runs (bit-exact on the device)
+    assert torch.equal(radius.cpu(), want_r)
+
+
+def test_get_obj_feats_template_sampling(net, dev):
+    """ViTEncoder.get_obj_feats (PEM/model/feature_extraction.py:152-172): template views -> 2048 FPS points + features."""
+    g = torch.Generator().manual_seed(5)
+    T = 3
+    rgbs = [torch.rand(1, 3, 224, 224, generator=g).to(dev) for _ in range(T)]
+    ptss = [((torch.rand(1, 5000, 3, generator=g) - 0.5) * 0.2).to(dev) for _ in range(T)]
+    chs = [torch.randint(0, 224 * 224, (1, 5000), generator=g).to(dev) for _ in range(T)]
+    with torch.no_grad():
+        p, f = net.feature_extraction.get_obj_feats(rgbs, ptss, chs)[:2]
+    assert p.shape == (1, 2048, 3) and f.shape == (1, 2048, 256)
+    allp = torch.cat(ptss, 1)[0]
+    # every sampled point is one of the template points, and FPS starts with the first one
+    member = (p[0][:, None, :] == allp[None, :, :]).all(-1).any(1)
+    assert bool(member.all()) and torch.equal(p[0, 0], allp[0])
