@@ -45,3 +45,44 @@ def test_ops_refuse_cpu_tensors():
         ops.furthest_point_sampling(torch.zeros(1, 8, 3), 4)
     with pytest.raises(RuntimeError):
         ops.ball_query(torch.zeros(1, 8, 3), torch.zeros(1, 8, 3).transpose(1, 2), 0.1, 4)
+
+
+def _gfx950_code_objects(path):
+    """Every gfx950 code object in the library's clang offload bundles (one bundle per translation unit)."""
+    import struct
+    data = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    at = data.find(magic)
+    while at >= 0:
+        count = struct.unpack_from("<Q", data, at + 24)[0]
+        off = at + 32
+        for _ in range(count):
+            o, s, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple and s:
+                yield data[at + o:at + o + s]
+        at = data.find(magic, at + 1)
+
+
+def test_no_packed_fp32_math_in_device_code(tmp_path):
+    """DESIGN.md (concurrency caveat): compiler-formed v_pk_{mul,add,fma}_f32 returned wrong lanes on MI355X while
+    f16-MFMA kernels ran on another stream, so the library is built with -fno-slp-vectorize -fno-vectorize and the
+    kernels spell their fp32 math as scalar fmaf.  This guards the flags: no packed-fp32 arithmetic in any kernel."""
+    import subprocess
+    from sam6d_hip import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("llvm-objdump not available")
+    n_obj = n_mfma = 0
+    for k, blob in enumerate(_gfx950_code_objects(_lib.LIB_PATH)):
+        p = tmp_path / ("co%d.elf" % k)
+        p.write_bytes(blob)
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(p)], capture_output=True, text=True, check=True).stdout
+        hits = re.findall(r"^\s*(v_pk_(?:fma|mul|add)_f32\b.*)$", asm, flags=re.M)
+        assert not hits, "packed fp32 math in code object %d: %s" % (k, hits[:3])
+        n_mfma += len(re.findall(r"\bv_mfma_", asm))
+        n_obj += 1
+    assert n_obj >= 5 and n_mfma > 0, "disassembly looks empty (%d code objects, %d MFMA)" % (n_obj, n_mfma)
