@@ -128,45 +128,74 @@ __global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_kernel(
 }
 
 // ===============================================================================================================
-// fp16 x3 split-precision form of the same fused kernel (default matmul mode): layer 1 (K = 6) stays on the exact
-// fp32 MFMA (3 instructions), layers 2 and 3 run on v_mfma_f32_32x32x16_f16 with hi/lo operands (gemm.hip explains
-// the arithmetic): 12 + 48 MFMAs of 32 cycles per 32-neighbour tile instead of 32 + 128 of 64 cycles.  Hidden
-// activations are split into fp16 hi/lo when they are written to the wave's LDS slab (h1 aliases h2: it is dead once
-// layer 2's products have been issued); weights are split once per workgroup while they are staged.
+// fp16 x3 split-precision form (default matmul mode), register-chained: activations never leave the registers.
+// Layer 1 (K = 6, exact fp32 MFMA) and layer 2 are computed TRANSPOSED (weights as the A operand, neighbours as the
+// columns), so each lane ends a layer holding, for its own neighbour, 16 channels per 32x32 tile -- which is exactly
+// the shape of the next product's K-operand (8 consecutive k per lane half) up to a fixed permutation of k: channel
+// (j&3) + 8*(2s + (j>>2)) + 4*fk sits at element j of k-step s, i.e. k with bits 2 and 3 swapped.  The weights are
+// staged into LDS with that permutation, so BN/ReLU -> fp16 hi/lo split -> pack is all that separates two layers (no
+// LDS slab, no wave barrier, no 16-bit stores).  Layer 3 consumes the layer-2 registers as its A operand (rows =
+// neighbours), so the max over the ball stays a register max per output channel as before.
+// 12 + 48 v_mfma_f32_32x32x16_f16 + 3 v_mfma_f32_32x32x2_f32 per 32-neighbour tile (2112 matrix-pipe cycles).
+// Persistent waves (3 workgroups of 4 waves per CU) stride over the points; the neighbour indices are loaded two
+// tiles ahead and the gathered coordinates one tile ahead, so the idx -> xyz dependent loads hide behind a tile's MFMAs.
 // ===============================================================================================================
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define PH_WAVES 4
 #define PH_L2 40   // halves per row of the K=32 images (80 B)
 #define PH_L3 72   // halves per row of the K=64 images (144 B = 9 x 16 B: 16 consecutive rows hit 16 different slots)
 #define PH_WBYTES (32 * 7 * 4 + 448 * 4 + 2 * 64 * PH_L2 * 2 + 2 * 128 * PH_L3 * 2)
-#define PH_HBYTES (2 * 32 * PH_L3 * 2)
 
-__global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_h3_kernel(
-    const float* __restrict__ pts, const int* __restrict__ idx, int N, int S, long total, const float* __restrict__ W1,
+__device__ __forceinline__ int pe_swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+// BN(eval) + ReLU + fp16 hi/lo split of the 8 accumulator registers [8*half, 8*half + 8) of one transposed tile; the
+// channels of those registers are base + 8*g + 4*fk + e (g = 2*half + (j>>2), e = j&3): two 16-byte constant reads each.
+__device__ __forceinline__ void pe_split8(const f32x16& acc, int half, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          int fk, half8& hi, half8& lo) {
+#pragma unroll
+  for (int g2 = 0; g2 < 2; ++g2) {
+    const int g = 2 * half + g2;
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[8 * g + 4 * fk]);
+    const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[8 * g + 4 * fk]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = fmaf(acc[4 * g + e], s4[e], h4[e]);
+      v = v > 0.f ? v : 0.f;
+      const _Float16 vh = (_Float16)v;
+      hi[4 * g2 + e] = vh;
+      lo[4 * g2 + e] = (_Float16)(v - (float)vh);
+    }
+  }
+}
+
+__global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void pe_mlp_max_h3_kernel(
+    const float* __restrict__ pts, const int* __restrict__ idx, int N, int S, int total, const float* __restrict__ W1,
     const float* __restrict__ sc1, const float* __restrict__ sh1, const float* __restrict__ W2, const float* __restrict__ sc2,
     const float* __restrict__ sh2, const float* __restrict__ W3, const float* __restrict__ sc3, const float* __restrict__ sh3,
     float* __restrict__ out, long ldo, int off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
   float* w1s = reinterpret_cast<float*>(lraw);                  // [32][7] fp32
   float* bn = w1s + 32 * 7;                                     // sc1 32 | sh1 32 | sc2 64 | sh2 64 | sc3 128 | sh3 128
-  _Float16* w2h = reinterpret_cast<_Float16*>(bn + 448);        // [64][40]
+  _Float16* w2h = reinterpret_cast<_Float16*>(bn + 448);        // [64][40], k permuted
   _Float16* w2l = w2h + 64 * PH_L2;
-  _Float16* w3h = w2l + 64 * PH_L2;                             // [128][72]
+  _Float16* w3h = w2l + 64 * PH_L2;                             // [128][72], k permuted
   _Float16* w3l = w3h + 128 * PH_L3;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  _Float16* hh = reinterpret_cast<_Float16*>(lraw + PH_WBYTES + wave * PH_HBYTES);  // hi image [32][72] (h1 uses [32][40])
-  _Float16* hl = hh + 32 * PH_L3;                                                    // lo image
-  for (int e = t; e < 32 * 6; e += PM_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e];
-  for (int e = t; e < 64 * 32; e += PM_WAVES * 64) {
+  for (int e = t; e < 32 * 6; e += PH_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e];
+  for (int e = t; e < 64 * 32; e += PH_WAVES * 64) {
     const float v = W2[e];
     const _Float16 h = (_Float16)v;
-    w2h[(e >> 5) * PH_L2 + (e & 31)] = h;
-    w2l[(e >> 5) * PH_L2 + (e & 31)] = (_Float16)(v - (float)h);
+    const int o = (e >> 5) * PH_L2 + pe_swap23(e & 31);
+    w2h[o] = h;
+    w2l[o] = (_Float16)(v - (float)h);
   }
-  for (int e = t; e < 128 * 64; e += PM_WAVES * 64) {
+  for (int e = t; e < 128 * 64; e += PH_WAVES * 64) {
     const float v = W3[e];
     const _Float16 h = (_Float16)v;
-    w3h[(e >> 6) * PH_L3 + (e & 63)] = h;
-    w3l[(e >> 6) * PH_L3 + (e & 63)] = (_Float16)(v - (float)h);
+    const int o = (e >> 6) * PH_L3 + pe_swap23(e & 63);
+    w3h[o] = h;
+    w3l[o] = (_Float16)(v - (float)h);
   }
   if (t < 32) { bn[t] = sc1[t]; bn[32 + t] = sh1[t]; }
   if (t < 64) { bn[64 + t] = sc2[t]; bn[128 + t] = sh2[t]; }
@@ -174,109 +203,110 @@ __global__ __launch_bounds__(PM_WAVES * 64) void pe_mlp_max_h3_kernel(
   __syncthreads();
   const int fr = lane & 31, fk = lane >> 5;
   const int ntile = S >> 5;
-  for (int i = 0; i < PM_PPW; ++i) {
-    const long p = ((long)blockIdx.x * PM_WAVES + wave) * PM_PPW + i;
-    if (p >= total) break;
-    const long b = p / N;
-    const float* pb = pts + b * N * 3;
-    const float qx = pts[p * 3] + 0.00000001f, qy = pts[p * 3 + 1] + 0.00000001f, qz = pts[p * 3 + 2] + 0.00000001f;
-    float mx[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int tile = 0; tile < ntile; ++tile) {
-      const int nb = idx[p * S + tile * 32 + fr];
-      const bool ok = nb >= 0 && nb < N;
-      const float x = ok ? pb[nb * 3] : 0.f, y = ok ? pb[nb * 3 + 1] : 0.f, z = ok ? pb[nb * 3 + 2] : 0.f;
-      const float f0 = fk ? (y - qy) : (x - qx);
-      const float f1 = fk ? x : (z - qz);
-      const float f2 = fk ? z : y;
-      f32x16 a1;
+  const int GW = gridDim.x * PH_WAVES;
+  float s3[4], h3[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0, w1s[fr * 7 + 0 + fk], a1, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1, w1s[fr * 7 + 2 + fk], a1, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2, w1s[fr * 7 + 4 + fk], a1, 0, 0, 0);
-      {
-        const float s = bn[fr], h = bn[32 + fr];
+  for (int c = 0; c < 4; ++c) { s3[c] = bn[192 + c * 32 + fr]; h3[c] = bn[320 + c * 32 + fr]; }
+  // tile A = being computed, B = next (indices loaded, coordinates in flight), C = the one after (indices in flight)
+  int pA = __builtin_amdgcn_readfirstlane(blockIdx.x * PH_WAVES + wave), tA = 0;
+  int pB = pA, tB = 1;
+  if (tB == ntile) { tB = 0; pB += GW; }
+  int pC = pB, tC = tB + 1;
+  if (tC == ntile) { tC = 0; pC += GW; }
+  float xA = 0.f, yA = 0.f, zA = 0.f, qxA = 0.f, qyA = 0.f, qzA = 0.f;
+  int nbB = 0;
+  if (pA < total) {
+    const int nb = idx[(long)pA * S + tA * 32 + fr];
+    const float* pb = pts + (long)(pA / N) * N * 3;
+    const bool ok = nb >= 0 && nb < N;
+    xA = ok ? pb[nb * 3] : 0.f; yA = ok ? pb[nb * 3 + 1] : 0.f; zA = ok ? pb[nb * 3 + 2] : 0.f;
+    qxA = pts[(long)pA * 3] + 0.00000001f; qyA = pts[(long)pA * 3 + 1] + 0.00000001f; qzA = pts[(long)pA * 3 + 2] + 0.00000001f;
+  }
+  if (pB < total) nbB = idx[(long)pB * S + tB * 32 + fr];
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0, so 0 is a neutral start for the max
+  int wrow = fr, wk = 8 * fk;  // this lane's row / k offset in the weight images
+  while (pA < total) {
+    // the weight reads are loop-invariant: keep them inside the loop (hoisted, they would not fit the register file)
+    asm volatile("" : "+v"(wrow), "+v"(wk));
+    // ---- prefetch: indices of tile C, coordinates of tile B
+    int nbC = 0;
+    if (pC < total) nbC = idx[(long)pC * S + tC * 32 + fr];
+    float xB = 0.f, yB = 0.f, zB = 0.f, qxB = 0.f, qyB = 0.f, qzB = 0.f;
+    if (pB < total) {
+      const float* pb = pts + (long)(pB / N) * N * 3;
+      const bool ok = nbB >= 0 && nbB < N;
+      xB = ok ? pb[nbB * 3] : 0.f; yB = ok ? pb[nbB * 3 + 1] : 0.f; zB = ok ? pb[nbB * 3 + 2] : 0.f;
+      qxB = pts[(long)pB * 3] + 0.00000001f; qyB = pts[(long)pB * 3 + 1] + 0.00000001f; qzB = pts[(long)pB * 3 + 2] + 0.00000001f;
+    }
+    // ---- layer 1 (transposed): D1T[ch][nb] = W1[ch][f] F[f][nb], f = 2i + fk: {x-qx, y-qy, z-qz, x, y, z}
+    const float f0 = fk ? (yA - qyA) : (xA - qxA);
+    const float f1 = fk ? xA : (zA - qzA);
+    const float f2 = fk ? zA : yA;
+    f32x16 a1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = fmaf(a1[r], s, h);
-          v = v > 0.f ? v : 0.f;
-          const _Float16 vh = (_Float16)v;
-          const int o = ((r & 3) + 8 * (r >> 2) + 4 * fk) * PH_L2 + fr;
-          hh[o] = vh;
-          hl[o] = (_Float16)(v - (float)vh);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // ---- layer 2: K = 32 -> 2 k-steps of 16, 2 column tiles
-      f32x16 a2[2];
+    for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 0 + fk], f0, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 2 + fk], f1, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 4 + fk], f2, a1, 0, 0, 0);
+    half8 h1h[2], h1l[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+    for (int s = 0; s < 2; ++s) pe_split8(a1, s, bn, bn + 32, wk >> 3, h1h[s], h1l[s]);
+    // ---- layer 2 (transposed): D2T[ch2][nb] = W2[ch2][k] H1T[k][nb]
+    f32x16 a2[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a2[c][r] = 0.f;
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int ks = 0; ks < 32; ks += 16) {
-        const half8 ah = *reinterpret_cast<const half8*>(&hh[fr * PH_L2 + ks + 8 * fk]);
-        const half8 al = *reinterpret_cast<const half8*>(&hl[fr * PH_L2 + ks + 8 * fk]);
+      for (int r = 0; r < 16; ++r) a2[c][r] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const half8 bh = *reinterpret_cast<const half8*>(&w2h[(c * 32 + fr) * PH_L2 + ks + 8 * fk]);
-          const half8 bl = *reinterpret_cast<const half8*>(&w2l[(c * 32 + fr) * PH_L2 + ks + 8 * fk]);
-          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2[c], 0, 0, 0);
-          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a2[c], 0, 0, 0);
-          a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a2[c], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // h1 image fully read (into registers) before h2 overwrites it
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float s = bn[64 + c * 32 + fr], h = bn[128 + c * 32 + fr];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = fmaf(a2[c][r], s, h);
-          v = v > 0.f ? v : 0.f;
-          const _Float16 vh = (_Float16)v;
-          const int o = ((r & 3) + 8 * (r >> 2) + 4 * fk) * PH_L3 + c * 32 + fr;
-          hh[o] = vh;
-          hl[o] = (_Float16)(v - (float)vh);
-        }
+        const half8 wh = *reinterpret_cast<const half8*>(&w2h[(c * 32 + wrow) * PH_L2 + 16 * s + wk]);
+        const half8 wl = *reinterpret_cast<const half8*>(&w2l[(c * 32 + wrow) * PH_L2 + 16 * s + wk]);
+        a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, h1l[s], a2[c], 0, 0, 0);
+        a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, h1h[s], a2[c], 0, 0, 0);
+        a2[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, h1h[s], a2[c], 0, 0, 0);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // ---- layer 3: K = 64 -> 4 k-steps, 4 column tiles
-      f32x16 a3[4];
+    }
+    // ---- layer 3: D3[nb][ch3] = H2[nb][k] W3[ch3][k]^T, k-step s = registers [8(s&1), +8) of tile s>>1
+    f32x16 a3[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a3[c][r] = 0.f;
+      for (int r = 0; r < 16; ++r) a3[c][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 64; ks += 16) {
-        const half8 ah = *reinterpret_cast<const half8*>(&hh[fr * PH_L3 + ks + 8 * fk]);
-        const half8 al = *reinterpret_cast<const half8*>(&hl[fr * PH_L3 + ks + 8 * fk]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const half8 bh = *reinterpret_cast<const half8*>(&w3h[(c * 32 + fr) * PH_L3 + ks + 8 * fk]);
-          const half8 bl = *reinterpret_cast<const half8*>(&w3l[(c * 32 + fr) * PH_L3 + ks + 8 * fk]);
-          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a3[c], 0, 0, 0);
-          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a3[c], 0, 0, 0);
-          a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a3[c], 0, 0, 0);
-        }
-      }
+    for (int s = 0; s < 4; ++s) {
+      half8 ah, al;
+      pe_split8(a2[s >> 1], s & 1, bn + 64 + 32 * (s >> 1), bn + 128 + 32 * (s >> 1), wk >> 3, ah, al);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float s = bn[192 + c * 32 + fr], h = bn[320 + c * 32 + fr];
-        float m = mx[c];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaf(a3[c][r], s, h));
-        mx[c] = m;
+        const half8 bh = *reinterpret_cast<const half8*>(&w3h[(c * 32 + wrow) * PH_L3 + 16 * s + wk]);
+        const half8 bl = *reinterpret_cast<const half8*>(&w3l[(c * 32 + wrow) * PH_L3 + 16 * s + wk]);
+        a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a3[c], 0, 0, 0);
+        a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a3[c], 0, 0, 0);
+        a3[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a3[c], 0, 0, 0);
       }
-      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float m = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
-      if (fk == 0) out[p * ldo + off + c * 32 + fr] = m;
+      float m = mx[c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaf(a3[c][r], s3[c], h3[c]));
+      mx[c] = m;
     }
+    if (tA == ntile - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float m = fmaxf(mx[c], xor32_f32(mx[c]));
+        if (fk == 0) out[(long)pA * ldo + off + c * 32 + fr] = m;
+        mx[c] = 0.f;
+      }
+    }
+    // ---- rotate the pipeline
+    pA = pB; tA = tB; pB = pC; tB = tC;
+    if (++tC == ntile) { tC = 0; pC += GW; }
+    nbB = nbC;
+    xA = xB; yA = yB; zA = zB; qxA = qxB; qyA = qyB; qzA = qzB;
   }
 }
 
@@ -290,7 +320,8 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
   const long per_block = PM_WAVES * PM_PPW;
   const dim3 grid((unsigned)((total + per_block - 1) / per_block));
   if (sam6d_get_matmul_mode() == 1) {
-    const size_t lds = (size_t)PH_WBYTES + PM_WAVES * PH_HBYTES;
+    SAM6D_REQUIRE(total < (1l << 31) / 64, "pe_mlp_max: B*N too large for 32-bit point ids (%ld)", total);
+    const size_t lds = (size_t)PH_WBYTES;
     static bool attr_h3 = false;
     if (!attr_h3) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_h3_kernel),
@@ -301,8 +332,11 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
       }
       attr_h3 = true;
     }
-    hipLaunchKernelGGL(pe_mlp_max_h3_kernel, grid, dim3(PM_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, total, W1,
-                       sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+    // persistent waves: 3 workgroups of 4 waves fit one CU's LDS (3 x 48.6 KB) -> 768 workgroups fill the 256 CUs once
+    const long want = (total + PH_WAVES - 1) / PH_WAVES;
+    const dim3 pgrid((unsigned)(want < 768 ? want : 768));
+    hipLaunchKernelGGL(pe_mlp_max_h3_kernel, pgrid, dim3(PH_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, (int)total,
+                       W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
   } else {
     const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
     static bool attr_set = false;

@@ -9,6 +9,7 @@
 #include "../../include/sam6d_hip.h"
 
 #include <float.h>
+#include <stdint.h>
 
 // =========================================================================================================
 // Farthest point sampling.
@@ -133,6 +134,95 @@ __global__ __launch_bounds__(THREADS) void fps_big_kernel(const float* __restric
   }
 }
 
+// Multi-workgroup variant for large clouds (the 210 000-point template cloud: 206 workgroups instead of one).
+// Every workgroup keeps 256 x PPT points and their running min-distances in registers, so a round costs one distance
+// update per point and no memory traffic beyond the grid-wide arg-max: the workgroup's best key goes into the round's
+// 64-bit slot with a device-scope atomic max, a device-scope arrival counter closes the round, and every workgroup reads
+// the winner back.  Same packed key and selection rule as above, so the result is identical to the one-workgroup kernels.
+// ws per cloud: m round slots + arrival counter + abort flag (64-bit each), zeroed by the host before the launch.
+// Co-residency: the host launches at most FPS_GRID_MAX_WG workgroups (one 256-thread workgroup per CU always fits
+// beside whatever else is running, and nothing ever waits on this kernel), and the spin has a bounded exit: a workgroup
+// that waits longer than FPS_SPIN_CAP polls raises the abort flag, every workgroup leaves, and out[b][m-1] is set to -1.
+#define FPS_GRID_MAX_WG 256
+#define FPS_SPIN_CAP (1u << 24)
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_grid_kernel(const float* __restrict__ xyz, int N, int m,
+                                                      unsigned long long* __restrict__ ws, int* __restrict__ out) {
+  __shared__ unsigned long long slots[2][4];
+  __shared__ unsigned long long s_best;
+  const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, t = threadIdx.x;
+  const float* p = xyz + (size_t)b * N * 3;
+  int* o = out + (size_t)b * m;
+  unsigned long long* best = ws + (size_t)b * (m + 2);
+  unsigned long long* arrived = best + m;
+  unsigned long long* abort_flag = best + m + 1;
+  float px[PPT], py[PPT], pz[PPT], td[PPT];
+  bool live[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = g * (256 * PPT) + i * 256 + t;
+    if (k < N) {
+      px[i] = p[(size_t)k * 3 + 0];
+      py[i] = p[(size_t)k * 3 + 1];
+      pz[i] = p[(size_t)k * 3 + 2];
+      const float mag = px[i] * px[i] + py[i] * py[i] + pz[i] * pz[i];
+      live[i] = !((double)mag <= 1e-3);
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+      live[i] = false;
+    }
+    td[i] = FLT_MAX;
+  }
+  if (g == 0 && t == 0) o[0] = 0;
+  int last = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = p[(size_t)last * 3 + 0], y1 = p[(size_t)last * 3 + 1], z1 = p[(size_t)last * 3 + 2];
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if (live[i]) {
+        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = (td[i] < d) ? td[i] : d;
+        td[i] = d2;
+        const unsigned int k = (unsigned int)(g * (256 * PPT) + i * 256 + t);
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(~k);
+        key = kk > key ? kk : key;
+      }
+    }
+    key = wave_max_u64(key);
+    if ((t & 63) == 0) slots[j & 1][t >> 6] = key;
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long mine = slots[j & 1][0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) mine = slots[j & 1][w] > mine ? slots[j & 1][w] : mine;
+      if (mine) __hip_atomic_fetch_max(&best[j], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrived, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long target = (unsigned long long)j * (unsigned long long)G;
+      unsigned int polls = 0;
+      bool dead = false;
+      while (__hip_atomic_load(arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || ++polls > FPS_SPIN_CAP) {
+          __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_best = dead ? ~0ull : __hip_atomic_load(&best[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned long long win = s_best;
+    if (win == ~0ull) {  // aborted (~0 is no valid key: the distance field would be a NaN pattern)
+      if (g == 0 && t == 0) o[m - 1] = -1;
+      return;
+    }
+    last = (win == 0ull) ? 0 : (int)(~(unsigned int)(win & 0xffffffffull));
+    if (g == 0 && t == 0) o[j] = last;
+  }
+}
+
 extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int* idx,
                                              void* stream) {
   SAM6D_REQUIRE(xyz && idx, "furthest_point_sampling: null pointer");
@@ -146,7 +236,19 @@ extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int
     hipLaunchKernelGGL((fps_reg_kernel<1024, 4>), dim3(B), dim3(1024), lds, s, xyz, N, m, idx);
   } else {
     SAM6D_REQUIRE(temp, "furthest_point_sampling: N=%d > 4096 needs the (B,N) float scratch `temp`", N);
-    hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx);
+    const long G = ((long)N + 1023) / 1024;  // 256 threads x 4 points per workgroup
+    const size_t ws_bytes = (size_t)B * (m + 2) * 8;
+    if (G * B <= FPS_GRID_MAX_WG && ws_bytes <= (size_t)B * N * 4 && ((uintptr_t)temp & 7) == 0) {
+      hipError_t e = hipMemsetAsync(temp, 0, ws_bytes, s);  // round slots, arrival counter, abort flag
+      if (e != hipSuccess) {
+        sam6d_set_error("furthest_point_sampling: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return (int)e;
+      }
+      hipLaunchKernelGGL((fps_grid_kernel<4>), dim3((unsigned)G, B), dim3(256), 0, s, xyz, N, m,
+                         reinterpret_cast<unsigned long long*>(temp), idx);
+    } else {
+      hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx);
+    }
   }
   SAM6D_LAUNCH_CHECK("furthest_point_sampling");
 }
@@ -214,9 +316,9 @@ extern "C" int sam6d_gather_rows(const float* feats, const int* idx, int B, int 
 // Ball query (ball_query.cpp:16-62): per query, the first `nsample` indices k (increasing) with d2 < r*r; the first
 // hit pre-fills every slot; no hit -> zeros.  d2 in plain fp32, source order, no FMA.
 // One wave per query: 64 candidates per step from an LDS-staged chunk of the cloud, ballot + prefix popcount keep
-// the reference's index order.  QPB queries per block, candidate chunks of CH points (48 KB) so any N works.
+// the reference's index order.  QPB queries per block, candidate chunks of CH points (24 KB: the 1024 workgroups of a 32 x 2048 query set are resident at once) so any N works.
 // =========================================================================================================
-#define BQ_CH 4096
+#define BQ_CH 2048
 #define BQ_QPB 64
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz, const float* __restrict__ xyz,
                                                          int N, int M, float radius2, int nsample,

@@ -191,6 +191,49 @@ def test_positional_encoding_golden(dev, W):
     assert float(dst[:, 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,N,S", [(3, 701, 32), (2, 1500, 64), (1, 5, 32), (40, 2048, 64)])
+def test_pe_mlp_max_register_chained_vs_exact_and_fp64(dev, W, B, N, S):
+    """The default (fp16x3, register-chained, persistent + prefetching) kernel against the exact-fp32 kernel and a
+    float64 recompute of QueryAndGroup -> SharedMLP -> max (fine_point_matching.py:126-139) on the same indices; ragged
+    point counts exercise the persistent loop's tail, (40, 2048, 64) more than one pass of the 768 workgroups."""
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("default (fp16x3) mode only")
+    gen = torch.Generator().manual_seed(B * 1000 + N + S)
+    pts = torch.rand(B, N, 3, generator=gen) - 0.5
+    idx = torch.randint(0, N, (B, N, S), generator=gen, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(N, dtype=torch.int32)[None]
+    L = W.pe["mlp"][0 if S == 32 else 1]
+
+    def run():
+        out = torch.full((B * N, 256), -7.0, device=dev)
+        _lib.call("sam6d_pe_mlp_max", pts.to(dev).data_ptr(), idx.to(dev).data_ptr(), B, N, S, L[0]["w"].data_ptr(),
+                  L[0]["scale"].data_ptr(), L[0]["shift"].data_ptr(), L[1]["w"].data_ptr(), L[1]["scale"].data_ptr(),
+                  L[1]["shift"].data_ptr(), L[2]["w"].data_ptr(), L[2]["scale"].data_ptr(), L[2]["shift"].data_ptr(),
+                  out.data_ptr(), 256, 128, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    got = run()
+    try:
+        _lib.call("sam6d_set_matmul_mode", 0)
+        exact = run()
+    finally:
+        _lib.call("sam6d_set_matmul_mode", 1)
+    assert float((got[:, :128] + 7.0).abs().max()) == 0.0, "columns outside [off, off+128) were touched"
+    if B * N * S <= 4_000_000:
+        nb = torch.gather(pts.double()[:, None].expand(B, N, N, 3), 2, idx.long()[..., None].expand(B, N, S, 3))
+        h = torch.cat([nb - (pts.double()[:, :, None] + 1e-8), nb], -1)
+        for l in L:
+            h = (h @ l["w"].double().cpu().t() * l["scale"].double().cpu() + l["shift"].double().cpu()).clamp(min=0)
+        want = h.max(2).values.reshape(B * N, 128).float()
+        _close(exact[:, 128:], want, 2e-5, "exact pe_mlp_max vs float64")
+        _close(got[:, 128:], want, 2e-5, "register-chained pe_mlp_max vs float64")
+    d = float((got - exact).abs().max())
+    print("\npe_mlp_max fp16x3 vs exact, B %d N %d S %d: max abs diff %.2e (scale %.2f)" % (B, N, S, d, float(exact.abs().max())))
+    assert d < 3e-6 * max(1.0, float(exact.abs().max()))
+
+
 def test_feature_similarity_golden(dev):
     from sam6d_hip import pem
     g = golden("similarity")

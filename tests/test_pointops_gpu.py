@@ -50,6 +50,43 @@ def test_fps_vs_oracle(dev, ext, B, N, m):
     assert torch.equal(got.cpu(), want)
 
 
+def test_fps_template_cloud_multi_workgroup(dev, ext):
+    """get_obj_feats' shape (feature_extraction.py:152-158): 42 x 5000 = 210 000 template points -> 2048, on the
+    multi-workgroup kernel (206 workgroups, grid-wide arg-max per round); identical to the C oracle and to the
+    one-workgroup global-memory kernel (reached here through a scratch pointer that is not 8-byte aligned)."""
+    import time
+    from oracle import pointops as P
+    from sam6d_hip import _lib
+    g = torch.Generator().manual_seed(42)
+    xyz = (torch.rand(1, 210000, 3, generator=g) - 0.5) * 0.3
+    xyz[0, ::7] *= 0.05  # origin-ball skip branch
+    want = P.furthest_point_sampling(xyz, 2048)
+    d = xyz.to(dev)
+    ext.furthest_point_sampling(d, 16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = ext.furthest_point_sampling(d, 2048)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    assert torch.equal(got.cpu(), want)
+    out = torch.empty(1, 2048, dtype=torch.int32, device=dev)
+    temp = torch.empty(210000 + 1, dtype=torch.float32, device=dev)
+    _lib.call("sam6d_furthest_point_sampling", d.data_ptr(), 1, 210000, 2048, temp.data_ptr() + 4, out.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert torch.equal(out.cpu(), want)
+    print("\nFPS 210000 -> 2048: multi-workgroup %.1f ms, one workgroup %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+
+
+def test_fps_many_large_clouds_fall_back_to_one_workgroup_each(dev, ext):
+    """More workgroups than the co-residency bound of the grid-synchronised kernel (60 clouds x 5 workgroups > 256)."""
+    from oracle import pointops as P
+    g = torch.Generator().manual_seed(7)
+    xyz = torch.rand(60, 5000, 3, generator=g) - 0.5
+    assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), 64).cpu(), P.furthest_point_sampling(xyz, 64))
+
+
 def test_fps_all_points_in_origin_ball(dev, ext):
     from oracle import pointops as P
     xyz = torch.full((1, 256, 3), 0.001)
