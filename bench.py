@@ -34,6 +34,7 @@ PROJP_FLOP_PER_CLOUD = 2.0 * 197 * 197 * 256 * 256  # 5.09 GFLOP: proj_p of the 
 RPE_FLOP_PER_QUERY = 2.0 * 197 * (3 * 256 * 32 + 4 * 256 + 4 * 32)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_FP16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def cpu_baseline(sd, nprop, threads):
@@ -164,6 +165,20 @@ def main():
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
+        # second roofline: the generic GEMM kernel has the largest total time of any kernel symbol (rocprof: 20 %); its dominant
+        # shape is the dense-token projection (2B x 2049 rows, K = N = 256), an HBM stream: algorithmic bytes = A read + C write
+        # (+ residual read) + weights, per launch, over the launches of the timed steps (HIP events on the launch stream).
+        gev = prof.get("gemm_dense_256", [])
+        gbytes = prof.get("gemm_dense_256_bytes", [])
+        roofline_gemm = None
+        if gev and len(gbytes) == len(gev):
+            g_ms = [a.elapsed_time(b) for a, b in gev]
+            g_gbs = sum(gbytes) / 1e9 / (sum(g_ms) * 1e-3)
+            roofline_gemm = {"bound": "hbm", "kernel": "gemm_nt_h3_kernel<128,128> on the dense-token projections (M = %d, K = N = 256, "
+                             "fp16x3 split-precision MFMA): %d launches per step" % (2 * B * 2049, len(gev) // max(1, args.steps)),
+                             "achieved": g_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g_gbs / PEAK_HBM_GBS, "traffic": None,
+                             "launch_ms": sum(g_ms) / len(g_ms), "launches_timed": len(g_ms),
+                             "algorithmic_mb_per_launch": sum(gbytes) / len(gbytes) / 1e6}
         res = {
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,6 +191,8 @@ def main():
                        "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding"},
             "roofline": roofline,
         }
+        if roofline_gemm is not None:
+            res["roofline_dense_gemm"] = roofline_gemm
         if args.cpu_proposals > 0 and world == 1:
             # host cores for the baseline: the GPU box gives a 1-GPU job a share of 16 cores (more threads only
             # oversubscribe the shared host: 256 threads ran the same port 20x slower)

@@ -162,8 +162,17 @@ def pack_pe(sd, device, pe):
 # ------------------------------------------------------------------------------------------------- primitives
 def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, residual=None, r_off=0, ldr=0,
          colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0):
-    _lib.call("sam6d_gemm_nt", _p(A, a_off), _p(W, w_off), _p(bias), _p(colscale), _p(residual, r_off), _p(out, c_off),
-              M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR, float(divisor), act, _s())
+    def launch():
+        _lib.call("sam6d_gemm_nt", _p(A, a_off), _p(W, w_off), _p(bias), _p(colscale), _p(residual, r_off), _p(out, c_off),
+                  M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR, float(divisor), act, _s())
+
+    if PROFILE is not None and batch == 1 and N == C and K == C and M >= 65536:
+        # bench.py's second roofline: the dense-token projections (M = 2B x 2049 rows, 256 -> 256) are HBM streams
+        PROFILE.setdefault("gemm_dense_256_bytes", []).append(4 * M * (K + N + (N if residual is not None else 0)) + 4 * N * K)
+        with _Timed("gemm_dense_256"):
+            launch()
+    else:
+        launch()
 
 
 def linear(x2d, lin, *, act=0, residual=None, out=None):
