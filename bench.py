@@ -174,9 +174,15 @@ def main():
         if gev and len(gbytes) == len(gev):
             g_ms = [a.elapsed_time(b) for a, b in gev]
             g_gbs = sum(gbytes) / 1e9 / (sum(g_ms) * 1e-3)
+            g_traffic = None
+            try:
+                gk = [k for k in tj["kernels"] if k.startswith("gemm_dense_256")]
+                g_traffic = tj["kernels"][gk[0]]["hbm_bytes_per_launch"] if (gk and B == B_PER_GPU) else None
+            except Exception:
+                g_traffic = None
             roofline_gemm = {"bound": "hbm", "kernel": "gemm_nt_h3_kernel<128,128> on the dense-token projections (M = %d, K = N = 256, "
                              "fp16x3 split-precision MFMA): %d launches per step" % (2 * B * 2049, len(gev) // max(1, args.steps)),
-                             "achieved": g_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g_gbs / PEAK_HBM_GBS, "traffic": None,
+                             "achieved": g_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g_gbs / PEAK_HBM_GBS, "traffic": g_traffic,
                              "launch_ms": sum(g_ms) / len(g_ms), "launches_timed": len(g_ms),
                              "algorithmic_mb_per_launch": sum(gbytes) / len(gbytes) / 1e6}
         res = {

@@ -24,7 +24,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Batch2 {
   int n2;
   long sA2, sW2, sC2, sR2;
+  int fold_nz;  // > 0: the batch elements are folded into grid.x (gemm_tile below), value = number of elements
 };
+
+// Workgroup -> (batch element z, row tile, column tile).  Workgroup ids are dealt round-robin to the 8 XCDs, each with its
+// own L2.
+//  * One big problem (tiles_n <= 8, tiles_m >= 32): the tiles_n column tiles of one row tile get ids 8 apart (same XCD,
+//    dispatched together), so the A rows they share come from HBM once and from that XCD's L2 afterwards; eight
+//    consecutive row tiles form a group of 8 * tiles_n ids (the last group is padded).
+//  * Batches of 8 or more (fold_nz): element z's tiles get the ids congruent to z mod 8, i.e. ONE XCD reads that element's
+//    A and W (with the elements on grid.z every XCD's L2 fetched every element: the 32 x 2049 x 2049 similarity GEMM pulled
+//    1.4 GB from HBM for 134 MB of operands, rocprof FETCH_SIZE).  Groups of 8 elements, the last group padded.
+template <int BM, int BN>
+__device__ __forceinline__ bool gemm_tile(int M, int N, const Batch2& b2, int& z, int& tm_, int& tn_) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if (b2.fold_nz > 0) {
+    const int per = tiles_m * tiles_n;
+    const int g = blockIdx.x / (8 * per), r = blockIdx.x % (8 * per);
+    z = g * 8 + (r & 7);
+    if (z >= b2.fold_nz) return false;
+    const int x = r >> 3;
+    tm_ = x % tiles_m;
+    tn_ = x / tiles_m;
+    return true;
+  }
+  z = blockIdx.z;
+  if (tiles_n <= 8 && tiles_m >= 32) {  // (small problems: plain order, no padding, every XCD gets tiles)
+    const int g = blockIdx.x / (8 * tiles_n), r = blockIdx.x % (8 * tiles_n);
+    tm_ = g * 8 + (r & 7);
+    tn_ = r >> 3;
+    return tm_ < tiles_m;  // padding of the last group (uniform for the workgroup)
+  }
+  tm_ = blockIdx.x % tiles_m;
+  tn_ = blockIdx.x / tiles_m;
+  return true;
+}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -37,25 +71,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   __shared__ float As[BM * GM_LD];
   __shared__ float Bs[BN * GM_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bz = blockIdx.z / b2.n2, bi = blockIdx.z % b2.n2;
+  int zz, tm_, tn_;
+  if (!gemm_tile<BM, BN>(M, N, b2, zz, tm_, tn_)) return;  // padding workgroup (uniform)
+  const int bz = zz / b2.n2, bi = zz % b2.n2;
   A += (size_t)bz * sA + (size_t)bi * b2.sA2;
   W += (size_t)bz * sW + (size_t)bi * b2.sW2;
   C += (size_t)bz * sC + (size_t)bi * b2.sC2;
   if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
-  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The tiles_n column
-  // tiles of one row tile get ids 8 apart (same XCD, dispatched together), so the A rows they share come from HBM once
-  // and from that XCD's L2 afterwards; eight consecutive row tiles form a group of 8 * tiles_n ids.
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  int tm_, tn_;
-  if (tiles_n <= 8 && tiles_m >= 32) {  // (small problems: plain order, no padding, every XCD gets tiles)
-    const int g = blockIdx.x / (8 * tiles_n), r = blockIdx.x % (8 * tiles_n);
-    tm_ = g * 8 + (r & 7);
-    tn_ = r >> 3;
-    if (tm_ >= tiles_m) return;  // padding of the last group (uniform for the workgroup)
-  } else {
-    tm_ = blockIdx.x % tiles_m;
-    tn_ = blockIdx.x / tiles_m;
-  }
   const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
@@ -198,25 +220,13 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   _Float16* Bh = Al + BM * H_LD;
   _Float16* Bl = Bh + BN * H_LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bz = blockIdx.z / b2.n2, bi = blockIdx.z % b2.n2;
+  int zz, tm_, tn_;
+  if (!gemm_tile<BM, BN>(M, N, b2, zz, tm_, tn_)) return;  // padding workgroup (uniform)
+  const int bz = zz / b2.n2, bi = zz % b2.n2;
   A += (size_t)bz * sA + (size_t)bi * b2.sA2;
   W += (size_t)bz * sW + (size_t)bi * b2.sW2;
   C += (size_t)bz * sC + (size_t)bi * b2.sC2;
   if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
-  // XCD-aware tile order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The tiles_n column
-  // tiles of one row tile get ids 8 apart (same XCD, dispatched together), so the A rows they share come from HBM once
-  // and from that XCD's L2 afterwards; eight consecutive row tiles form a group of 8 * tiles_n ids.
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  int tm_, tn_;
-  if (tiles_n <= 8 && tiles_m >= 32) {  // (small problems: plain order, no padding, every XCD gets tiles)
-    const int g = blockIdx.x / (8 * tiles_n), r = blockIdx.x % (8 * tiles_n);
-    tm_ = g * 8 + (r & 7);
-    tn_ = r >> 3;
-    if (tm_ >= tiles_m) return;  // padding of the last group (uniform for the workgroup)
-  } else {
-    tm_ = blockIdx.x % tiles_m;
-    tn_ = blockIdx.x / tiles_m;
-  }
   const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 
@@ -413,9 +423,11 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   const bool big = blocks128 >= 1024 && (M > 256 || M % 128 == 0);
   const int tm = cdiv(M, big ? 128 : 64), tn = cdiv(N, big ? 128 : 64);
   // all tiles on x (2^31 limit) in the XCD-aware order the kernels decode; groups of 8 row tiles are padded
-  const long tiles = (tn <= 8 && tm >= 32) ? (long)cdiv(tm, 8) * 8 * tn : (long)tm * tn;
+  const bool fold = nz >= 8;  // batch elements folded into grid.x, one XCD per element (gemm_tile)
+  const long tiles = fold ? (long)cdiv(nz, 8) * 8 * tm * tn : (tn <= 8 && tm >= 32) ? (long)cdiv(tm, 8) * 8 * tn : (long)tm * tn;
   SAM6D_REQUIRE(tiles < 2147483647L, "gemm_nt: too many tiles for one launch");
-  dim3 grid((unsigned)tiles, 1, nz);
+  dim3 grid((unsigned)tiles, 1, fold ? 1 : nz);
+  b2.fold_nz = fold ? nz : 0;
   hipStream_t st = (hipStream_t)stream;
 #define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
@@ -438,13 +450,13 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
                              const float* residual, float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr,
                              int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream) {
   return gemm_launch(A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
-                     Batch2{1, 0, 0, 0, 0}, divisor, act, stream);
+                     Batch2{1, 0, 0, 0, 0, 0}, divisor, act, stream);
 }
 
 extern "C" int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int K, long lda, long ldw, long ldc,
                                 int batch, long sA, long sW, long sC, int batch2, long sA2, long sW2, long sC2, void* stream) {
   return gemm_launch(A, W, nullptr, nullptr, nullptr, C, M, N, K, lda, ldw, ldc, 0, batch, sA, sW, sC, 0,
-                     Batch2{batch2, sA2, sW2, sC2, 0}, 1.0f, 0, stream);
+                     Batch2{batch2, sA2, sW2, sC2, 0, 0}, 1.0f, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
