@@ -272,6 +272,19 @@ int sam6d_mask_to_indices(const unsigned char* keep, int N, long long* idx, int*
  * tensor of any dtype: dst[j,:] = src[idx[j],:], rows of row_bytes bytes, idx (M) i64 (negative = from the end;
  * out-of-range rows come back zero). */
 int sam6d_take_rows(const void* src, const long long* idx, long n_src, int M, long row_bytes, void* dst, void* stream);
+/* replaces mask_to_rle(force_binary_mask(mask)) of convert_npz_to_json, the `segmentation` field of detection_ism.json
+ * (ISM/model/utils.py:25-43, 199-216; ISM/utils/bbox_utils.py:190-192): uncompressed COCO RLE of (mask > 0), runs counted in
+ * column-major order starting with the zero run.  masks (N,H,W) f32.  Two calls: nruns[i] (N) i32 = number of counts of
+ * mask i; then, with offsets (N+1) i64 = exclusive prefix sum of nruns, counts[offsets[i] .. offsets[i+1]) i32 = its runs
+ * (a mask whose offsets do not match its run count is left unwritten). */
+int sam6d_mask_rle_count(const float* masks, int N, int H, int W, int* nruns, void* stream);
+int sam6d_mask_rle_encode(const float* masks, int N, int H, int W, const long long* offsets, int* counts, void* stream);
+/* the inverse, as PEM's get_test_data reads the file back (cocomask.decode of an uncompressed RLE,
+ * PEM/run_inference_custom_pytorch.py:308-317; same format as ISM/segment_anything/utils/amg.py:138-150):
+ * masks (N,H,W) u8 from counts / offsets as above; ws_ends = i32 scratch as long as counts.  Positions beyond the
+ * encoded runs come back 0. */
+int sam6d_mask_rle_decode(const int* counts, const long long* offsets, int N, int H, int W, int* ws_ends,
+                          unsigned char* masks, void* stream);
 /* replaces torchvision.ops.nms as Detections.apply_nms (ISM/model/utils.py:121-124, group == NULL) and
  * apply_nms_per_object_id (:107-117, group = object_ids) call it: boxes (N,4) f32 xyxy, scores (N) f32.
  * keep_idx (N) i64 receives the surviving indices, ids ascending, score descending inside an id (stable); count[0] = K.

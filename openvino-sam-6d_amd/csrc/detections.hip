@@ -215,3 +215,168 @@ extern "C" int sam6d_nms(const float* boxes, const float* scores, const long lon
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(threads), 0, s, mask, order, N, nw, keep_idx, count);
   SAM6D_LAUNCH_CHECK("nms");
 }
+
+// =========================================================================================================
+// Uncompressed COCO RLE of the detection masks: the `segmentation` field of detection_ism.json
+// (mask_to_rle(force_binary_mask(mask)), ISM/model/utils.py:25-43, 199-216; utils/bbox_utils.py:190-192) and its
+// inverse as PEM reads it back (cocomask.decode of an uncompressed RLE, PEM/run_inference_custom_pytorch.py:312-317;
+// same format as segment_anything/utils/amg.py:107-150).
+// Runs are counted over (mask > 0) in COLUMN-major order (i = x*H + y), starting with the zero run (length 0 when
+// pixel 0 is set): boundaries p_0 < p_1 < ... are the positions whose value differs from the previous one (value -1 := 0);
+// counts = [p_0, p_1 - p_0, ..., H*W - p_last] (a single H*W for an empty mask).
+// One workgroup per mask; thread t owns a contiguous chunk of columns = a contiguous piece of the column-major order.
+// The reference walks the 307 200 pixels of every mask in a Python loop.
+// =========================================================================================================
+struct RleChunk {
+  int nb;    // boundaries inside the chunk
+  int last;  // position of the chunk's last boundary, -1 if none
+};
+
+__device__ __forceinline__ RleChunk rle_walk(const float* __restrict__ m, int H, int W, int c0, int c1, int prev_pos,
+                                             int* __restrict__ out) {
+  RleChunk r{0, -1};
+  if (c0 >= c1) return r;
+  bool pv = (c0 > 0) ? (m[(size_t)(H - 1) * W + (c0 - 1)] > 0.f) : false;
+  for (int c = c0; c < c1; ++c) {
+    for (int y = 0; y < H; ++y) {
+      const bool v = m[(size_t)y * W + c] > 0.f;
+      if (v != pv) {
+        const int p = c * H + y;
+        if (out) {
+          out[r.nb] = p - prev_pos;
+          prev_pos = p;
+        }
+        ++r.nb;
+        r.last = p;
+        pv = v;
+      }
+    }
+  }
+  return r;
+}
+
+// exclusive scan of nb and "latest boundary so far" over the 256 chunks (positions grow with the chunk index: max = latest)
+__device__ __forceinline__ void rle_scan(RleChunk mine, int t, int* s_nb, int* s_last, int& off, int& prev, int& total, int& last_all) {
+  s_nb[t] = mine.nb;
+  s_last[t] = mine.last;
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0, lp = -1;
+    for (int i = 0; i < 256; ++i) {
+      const int n = s_nb[i], l = s_last[i];
+      s_nb[i] = acc;
+      s_last[i] = lp;
+      acc += n;
+      lp = l >= 0 ? l : lp;
+    }
+    s_nb[256] = acc;
+    s_last[256] = lp;
+  }
+  __syncthreads();
+  off = s_nb[t];
+  prev = s_last[t];
+  total = s_nb[256];
+  last_all = s_last[256];
+}
+
+__global__ __launch_bounds__(256) void rle_count_kernel(const float* __restrict__ masks, int H, int W, int* __restrict__ nruns) {
+  __shared__ int s_nb[257], s_last[257];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float* m = masks + (size_t)n * H * W;
+  const int cpt = (W + 255) / 256;
+  const RleChunk mine = rle_walk(m, H, W, min(W, t * cpt), min(W, (t + 1) * cpt), 0, nullptr);
+  int off, prev, total, last_all;
+  rle_scan(mine, t, s_nb, s_last, off, prev, total, last_all);
+  if (t == 0) nruns[n] = total + 1;
+}
+
+__global__ __launch_bounds__(256) void rle_encode_kernel(const float* __restrict__ masks, int H, int W,
+                                                         const long long* __restrict__ offsets, int* __restrict__ counts) {
+  __shared__ int s_nb[257], s_last[257];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const float* m = masks + (size_t)n * H * W;
+  const int cpt = (W + 255) / 256;
+  const int c0 = min(W, t * cpt), c1 = min(W, (t + 1) * cpt);
+  const RleChunk mine = rle_walk(m, H, W, c0, c1, 0, nullptr);
+  int off, prev, total, last_all;
+  rle_scan(mine, t, s_nb, s_last, off, prev, total, last_all);
+  int* out = counts + offsets[n];
+  if ((long long)(total + 1) != offsets[n + 1] - offsets[n]) return;  // offsets do not belong to these masks: write nothing
+  rle_walk(m, H, W, c0, c1, prev >= 0 ? prev : 0, out + off);
+  if (t == 0) out[total] = H * W - (last_all >= 0 ? last_all : 0);
+}
+
+// decode, step 1: ends[o] = inclusive prefix sum of the mask's counts (one workgroup per mask, chunked scan)
+__global__ __launch_bounds__(256) void rle_prefix_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                         int* __restrict__ ends) {
+  __shared__ long long s_sum[257];
+  const int n = blockIdx.x, t = threadIdx.x;
+  const long long o0 = offsets[n], o1 = offsets[n + 1];
+  const long long len = o1 - o0, per = (len + 255) / 256;
+  const long long a = min(len, t * per), b = min(len, (t + 1) * per);
+  long long s = 0;
+  for (long long i = a; i < b; ++i) s += counts[o0 + i];
+  s_sum[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    long long acc = 0;
+    for (int i = 0; i < 256; ++i) {
+      const long long v = s_sum[i];
+      s_sum[i] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  long long run = s_sum[t];
+  for (long long i = a; i < b; ++i) {
+    run += counts[o0 + i];
+    ends[o0 + i] = (int)min(run, (long long)0x7fffffff);
+  }
+}
+
+// decode, step 2: pixel (y, x) sits at column-major position i = x*H + y; it belongs to run j = first j with ends[j] > i and
+// is set when j is odd.  Positions past the last run (counts that do not add up to H*W) come back 0.
+__global__ __launch_bounds__(256) void rle_fill_kernel(const int* __restrict__ ends, const long long* __restrict__ offsets, int H,
+                                                       int W, unsigned char* __restrict__ masks) {
+  const int n = blockIdx.y;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)H * W) return;
+  const int y = (int)(e / W), x = (int)(e % W);
+  const int i = x * H + y;
+  const long long o0 = offsets[n];
+  const int len = (int)(offsets[n + 1] - o0);
+  const int* en = ends + o0;
+  int lo = 0, hi = len;  // first j in [0, len) with en[j] > i
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (en[mid] > i) hi = mid; else lo = mid + 1;
+  }
+  masks[(size_t)n * H * W + e] = (lo < len) ? (unsigned char)(lo & 1) : (unsigned char)0;
+}
+
+extern "C" int sam6d_mask_rle_count(const float* masks, int N, int H, int W, int* nruns, void* stream) {
+  SAM6D_REQUIRE(masks && nruns, "mask_rle_count: null pointer");
+  SAM6D_REQUIRE(N >= 0 && H > 0 && W > 0 && (long)H * W < 2147483647L, "mask_rle_count: bad sizes N=%d H=%d W=%d", N, H, W);
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(rle_count_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, masks, H, W, nruns);
+  SAM6D_LAUNCH_CHECK("mask_rle_count");
+}
+
+extern "C" int sam6d_mask_rle_encode(const float* masks, int N, int H, int W, const long long* offsets, int* counts, void* stream) {
+  SAM6D_REQUIRE(masks && offsets && counts, "mask_rle_encode: null pointer");
+  SAM6D_REQUIRE(N >= 0 && H > 0 && W > 0 && (long)H * W < 2147483647L, "mask_rle_encode: bad sizes N=%d H=%d W=%d", N, H, W);
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(rle_encode_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, masks, H, W, offsets, counts);
+  SAM6D_LAUNCH_CHECK("mask_rle_encode");
+}
+
+extern "C" int sam6d_mask_rle_decode(const int* counts, const long long* offsets, int N, int H, int W, int* ws_ends,
+                                     unsigned char* masks, void* stream) {
+  SAM6D_REQUIRE(counts && offsets && ws_ends && masks, "mask_rle_decode: null pointer");
+  SAM6D_REQUIRE(N >= 0 && N <= 65535 && H > 0 && W > 0 && (long)H * W < 2147483647L, "mask_rle_decode: bad sizes N=%d H=%d W=%d", N, H, W);
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rle_prefix_kernel, dim3(N), dim3(256), 0, s, counts, offsets, ws_ends);
+  hipLaunchKernelGGL(rle_fill_kernel, dim3((unsigned)(((long)H * W + 255) / 256), N), dim3(256), 0, s, ws_ends, offsets, H, W, masks);
+  SAM6D_LAUNCH_CHECK("mask_rle_decode");
+}

@@ -68,6 +68,9 @@ SIGNATURES = {
     "sam6d_detections_small_keep": [c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p],
     "sam6d_mask_to_indices": [c_p, c_i, c_p, c_p, c_p],
     "sam6d_take_rows": [c_p, c_p, c_l, c_i, c_l, c_p, c_p],
+    "sam6d_mask_rle_count": [c_p, c_i, c_i, c_i, c_p, c_p],
+    "sam6d_mask_rle_encode": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_mask_rle_decode": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_nms_workspace_bytes": [c_i],
     "sam6d_nms": [c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_mask_bbox": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -173,3 +173,64 @@ def nms(boxes, scores, iou_threshold, object_ids=None):
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=boxes.device)
     _lib.call("sam6d_nms", _p(boxes), _p(scores), _p(grp), N, float(iou_threshold), _p(keep), _p(cnt), _p(ws), nbytes, _s())
     return keep[: int(cnt.item())]
+
+
+def mask_rle_encode(masks):
+    """Uncompressed COCO RLE of (masks > 0), column-major runs starting with the zero run
+    (mask_to_rle(force_binary_mask(m)), ISM/model/utils.py:25-43, 211-213).  masks (N,H,W) on the HIP device (any real dtype).
+    Returns (counts i32 (total,), offsets i64 (N+1,)) on the device: mask i's runs are counts[offsets[i]:offsets[i+1]]."""
+    if not masks.is_cuda:
+        raise RuntimeError("mask_rle_encode: masks must be a HIP device tensor (no CPU path)")
+    if masks.dim() != 3:
+        raise RuntimeError("mask_rle_encode: masks must be (N,H,W)")
+    m = masks.to(torch.float32).contiguous()
+    N, H, W = m.shape
+    if N == 0:
+        return torch.empty(0, dtype=torch.int32, device=m.device), torch.zeros(1, dtype=torch.int64, device=m.device)
+    with torch.cuda.device(m.device):
+        nruns = torch.empty(N, dtype=torch.int32, device=m.device)
+        _lib.call("sam6d_mask_rle_count", _p(m), N, H, W, _p(nruns), _s())
+        offsets = torch.zeros(N + 1, dtype=torch.int64, device=m.device)
+        if N:
+            offsets[1:] = torch.cumsum(nruns.to(torch.int64), 0)
+        total = int(offsets[-1].item())
+        counts = torch.empty(total, dtype=torch.int32, device=m.device)
+        _lib.call("sam6d_mask_rle_encode", _p(m), N, H, W, _p(offsets), _p(counts), _s())
+    return counts, offsets
+
+
+def mask_to_rle(masks):
+    """List of {"counts": [...], "size": [H, W]} dicts, one per mask: what convert_npz_to_json stores under "segmentation"
+    (ISM/model/utils.py:199-216)."""
+    counts, offsets = mask_rle_encode(masks)
+    c = counts.cpu().tolist()
+    o = offsets.cpu().tolist()
+    H, W = int(masks.shape[1]), int(masks.shape[2])
+    return [{"counts": c[o[i]:o[i + 1]], "size": [H, W]} for i in range(len(o) - 1)]
+
+
+def rle_to_mask(rles, device):
+    """Inverse of mask_to_rle for a list of uncompressed RLE dicts of one size -> (N,H,W) uint8 on `device` (what
+    cocomask.decode returns in PEM/run_inference_custom_pytorch.py:312-317)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("rle_to_mask: needs a HIP device (no CPU path)")
+    if len(rles) == 0:
+        return torch.zeros(0, 0, 0, dtype=torch.uint8, device=device)
+    H, W = (int(v) for v in rles[0]["size"])
+    flat, offs = [], [0]
+    for r in rles:
+        if [int(v) for v in r["size"]] != [H, W]:
+            raise RuntimeError("rle_to_mask: all masks must have one size")
+        if isinstance(r["counts"], (str, bytes)):
+            raise RuntimeError("rle_to_mask: compressed RLE strings are pycocotools' own format; only uncompressed counts are read")
+        flat.extend(int(v) for v in r["counts"])
+        offs.append(len(flat))
+    N = len(rles)
+    with torch.cuda.device(device):
+        counts = torch.tensor(flat if flat else [0], dtype=torch.int32, device=device)
+        offsets = torch.tensor(offs, dtype=torch.int64, device=device)
+        ends = torch.empty_like(counts)
+        out = torch.empty(N, H, W, dtype=torch.uint8, device=device)
+        _lib.call("sam6d_mask_rle_decode", _p(counts), _p(offsets), N, H, W, _p(ends), _p(out), _s())
+    return out

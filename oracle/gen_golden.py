@@ -16,6 +16,7 @@ Usage:  python oracle/gen_golden.py [--only name,...]
 import argparse
 import hashlib
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -630,8 +631,43 @@ def fx_ism():
          boxes=boxes.to(torch.int32), iou=iou, iou_quirk=np.float32(iou_q), final=fin)
 
 
+def fx_rle():
+    """the `segmentation` field of detection_ism.json.  ISM/model/utils.py (mask_to_rle, convert_npz_to_json) imports
+    torchvision, which is not installed, so it cannot be imported; the SAME uncompressed COCO RLE format is produced and read by the
+    reference's segment_anything/utils/amg.py (mask_to_rle_pytorch :107-135, rle_to_mask :138-150), which IS importable: it is run
+    here on seeded masks and edge cases and pins oracle/ism_oracle.py's restatement of mask_to_rle / rle_to_mask."""
+    spec = importlib.util.spec_from_file_location("ref_amg", os.path.join(ISM, "segment_anything", "utils", "amg.py"))
+    amg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(amg)
+    g = torch.Generator().manual_seed(21)
+    H, W = 60, 80
+    masks = torch.zeros(8, H, W)
+    for i in range(5):  # blobs: random rectangles with holes
+        x0 = int(torch.randint(0, W - 30, (1,), generator=g)); y0 = int(torch.randint(0, H - 30, (1,), generator=g))
+        w = int(torch.randint(8, 30, (1,), generator=g)); h = int(torch.randint(8, 30, (1,), generator=g))
+        masks[i, y0:y0 + h, x0:x0 + w] = 1
+        masks[i][torch.rand(H, W, generator=g) < 0.05] = 0
+    masks[5] = (torch.rand(H, W, generator=g) < 0.5).float()  # noise: thousands of runs
+    masks[6] = 1.0                                             # full: counts = [0, H*W]
+    masks[7, 0, 0] = 1.0                                       # first pixel set, and (masks[7] otherwise empty)
+    masks[4, H - 1, W - 1] = 1.0                               # last pixel set
+    rles = amg.mask_to_rle_pytorch(masks > 0)
+    flat, offs = [], [0]
+    for i, r in enumerate(rles):
+        assert r["size"] == [H, W]
+        o = IO.mask_to_rle(IO.force_binary_mask(masks[i].numpy()))
+        assert o == {"counts": r["counts"], "size": r["size"]}, "oracle mask_to_rle differs from the reference's RLE (mask %d)" % i
+        assert o == IO.mask_to_rle_loop(IO.force_binary_mask(masks[i].numpy()))
+        back = amg.rle_to_mask(r)
+        assert np.array_equal(back, masks[i].numpy() > 0) and np.array_equal(IO.rle_to_mask(r), back)
+        flat.extend(r["counts"]); offs.append(len(flat))
+    empty = amg.mask_to_rle_pytorch(torch.zeros(1, H, W, dtype=torch.bool))[0]
+    assert empty["counts"] == [H * W] == IO.mask_to_rle(np.zeros((H, W)))["counts"]
+    save("rle", seed=21, masks=masks.to(torch.uint8), counts=np.asarray(flat, np.int32), offsets=np.asarray(offs, np.int64))
+
+
 ALL = ["pointops", "pairwise", "geo", "transformer", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
-       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "ism"]
+       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "ism", "rle"]
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -640,7 +676,7 @@ if __name__ == "__main__":
     todo = [s for s in a.only.split(",") if s] or ALL
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    pem = [t for t in todo if t != "ism"]
+    pem = [t for t in todo if t not in ("ism", "rle")]
     if pem:
         ext, mods = import_reference_pem()
         for t in pem:
@@ -649,4 +685,7 @@ if __name__ == "__main__":
     if "ism" in todo:
         print("[gen_golden] ism")
         fx_ism()
+    if "rle" in todo:
+        print("[gen_golden] rle")
+        fx_rle()
     print("done")

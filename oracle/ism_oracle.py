@@ -166,3 +166,72 @@ def nms_per_object_id(boxes, scores, object_ids, thresh):
         sel = object_ids == oid
         out.append(all_idx[sel][nms(boxes[sel].float(), scores[sel].float(), thresh)])
     return torch.cat(out) if out else torch.zeros(0, dtype=torch.int64)
+
+
+# --------------------------------------------------------------- detection_ism.json (ISM/model/utils.py)
+LMO_OBJECT_IDS = np.array([1, 5, 6, 8, 9, 10, 11, 12])  # ISM/model/utils.py:8-22: LM-O's object ids (BOP numbering)
+
+
+def force_binary_mask(mask, threshold=0.0):
+    """ISM/utils/bbox_utils.py:190-192."""
+    return np.where(np.asarray(mask) > threshold, 1, 0)
+
+
+def mask_to_rle_loop(binary_mask):
+    """ISM/model/utils.py:25-43, statement by statement (small masks only)."""
+    counts = []
+    last, run = 0, 0
+    for elem in np.asarray(binary_mask).ravel(order="F"):
+        if elem != last:
+            counts.append(run)
+            run = 0
+            last = elem
+        run += 1
+    counts.append(run)
+    return {"counts": counts, "size": list(np.asarray(binary_mask).shape)}
+
+
+def mask_to_rle(binary_mask):
+    """Same result as mask_to_rle_loop, vectorised: boundaries of the column-major sequence (value before the start = 0)."""
+    m = np.asarray(binary_mask)
+    flat = (m.ravel(order="F") != 0).astype(np.int8)
+    prev = np.concatenate(([0], flat[:-1]))
+    pos = np.flatnonzero(flat != prev)
+    edges = np.concatenate(([0], pos, [flat.size]))
+    return {"counts": np.diff(edges).tolist(), "size": list(m.shape)}
+
+
+def rle_to_mask(rle):
+    """ISM/segment_anything/utils/amg.py:138-150 (what pycocotools' decode returns for an uncompressed RLE)."""
+    h, w = rle["size"]
+    counts = np.asarray(rle["counts"], dtype=np.int64)
+    vals = (np.arange(len(counts)) & 1).astype(bool)
+    flat = np.repeat(vals, counts)
+    out = np.zeros(h * w, dtype=bool)
+    out[: min(flat.size, h * w)] = flat[: h * w]
+    return out.reshape(w, h).transpose()
+
+
+def xyxy_to_xywh(bbox):
+    """ISM/utils/bbox_utils.py:129-138 (the 2-D branch has no +1; the 1-D branch has)."""
+    bbox = np.asarray(bbox)
+    if bbox.ndim == 1:
+        x1, y1, x2, y2 = bbox
+        return [x1, y1, x2 - x1 + 1, y2 - y1 + 1]
+    if bbox.ndim == 2:
+        return np.stack([bbox[:, 0], bbox[:, 1], bbox[:, 2] - bbox[:, 0], bbox[:, 3] - bbox[:, 1]], axis=1)
+    raise ValueError("bbox must be a numpy array of shape (4,) or (N, 4)")
+
+
+def detections_to_records(object_ids, scores, boxes_xyxy, masks, scene_id=0, frame_id=0, runtime=0, dataset_name="Custom"):
+    """Detections.save_to_file (ISM/model/utils.py:153-173) followed by convert_npz_to_json (:199-216), without the file in between:
+    the list that save_json_bop23 dumps as detection_ism.json."""
+    object_ids = np.asarray(object_ids)
+    cat = object_ids + 1 if dataset_name != "lmo" else LMO_OBJECT_IDS[object_ids]
+    bbox = xyxy_to_xywh(np.asarray(boxes_xyxy))
+    out = []
+    for i in range(len(bbox)):
+        out.append({"scene_id": int(scene_id), "image_id": int(frame_id), "category_id": int(cat[i]), "bbox": bbox[i].tolist(),
+                    "score": float(np.asarray(scores)[i]), "time": float(runtime),
+                    "segmentation": mask_to_rle(force_binary_mask(np.asarray(masks)[i]))})
+    return out

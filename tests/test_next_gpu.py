@@ -248,3 +248,108 @@ def test_proposal_geometry_random_masks_vs_oracle(dev):
         assert geom["bbox"][i].cpu().tolist() == o["bbox"] and nk == len(o["choose"])
         assert np.array_equal(geom["choose"][i, :nk].cpu().numpy(), o["choose"].astype(np.int32))
         assert np.array_equal(geom["cloud"][i, :nk].cpu().numpy(), o["cloud"])
+
+
+# ------------------------------------------------------------------------------------------ detection_ism.json
+def _blob_masks(g, N, H, W):
+    m = torch.zeros(N, H, W)
+    for i in range(N):
+        x0 = int(torch.randint(0, max(1, W - 8), (1,), generator=g)); y0 = int(torch.randint(0, max(1, H - 8), (1,), generator=g))
+        w = int(torch.randint(1, max(2, W // 2), (1,), generator=g)); h = int(torch.randint(1, max(2, H // 2), (1,), generator=g))
+        m[i, y0:y0 + h, x0:x0 + w] = torch.rand(min(h, H - y0), min(w, W - x0), generator=g)  # soft values in (0, 1)
+        m[i][torch.rand(H, W, generator=g) < 0.02] = 0
+    return m
+
+
+def test_mask_rle_golden_bit_exact(dev):
+    """RLE kernels vs the counts the reference's own amg.mask_to_rle_pytorch produced (tests/golden/rle.npz)."""
+    from sam6d_hip import ism
+    from tests._util import golden
+    g = golden("rle")
+    masks = torch.from_numpy(g["masks"]).to(dev)
+    counts, offs = ism.mask_rle_encode(masks)
+    assert np.array_equal(offs.cpu().numpy(), g["offsets"]) and np.array_equal(counts.cpu().numpy(), g["counts"])
+    rles = ism.mask_to_rle(masks)
+    assert rles[6] == {"counts": [0, 60 * 80], "size": [60, 80]} and rles[7]["counts"] == [0, 1, 60 * 80 - 1]
+    back = ism.rle_to_mask(rles, dev)
+    assert back.dtype == torch.uint8 and np.array_equal(back.cpu().numpy(), g["masks"])
+
+
+@pytest.mark.parametrize("N,H,W", [(24, 480, 640), (3, 7, 300), (2, 1, 1), (5, 33, 1), (4, 1, 77), (1, 257, 513), (0, 8, 8)])
+def test_mask_rle_vs_oracle_and_round_trip(dev, N, H, W):
+    from oracle import ism_oracle as O
+    from sam6d_hip import ism
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    masks = _blob_masks(g, N, H, W)
+    if N > 1:
+        masks[0] = 0
+        masks[1] = (torch.rand(H, W, generator=g) < 0.5).float()  # noise: the most runs a mask can have
+    rles = ism.mask_to_rle(masks.to(dev))
+    assert len(rles) == N
+    for i in range(N):
+        assert rles[i] == O.mask_to_rle(O.force_binary_mask(masks[i].numpy())), "mask %d" % i
+        assert sum(rles[i]["counts"]) == H * W
+    if N:
+        back = ism.rle_to_mask(rles, dev).cpu().numpy()
+        assert np.array_equal(back, (masks.numpy() > 0).astype(np.uint8))
+        # counts that stop short of H*W decode to zeros beyond the encoded runs (amg.rle_to_mask would leave garbage there)
+        short = [{"counts": r["counts"][:-1], "size": r["size"]} for r in rles]
+        dec = ism.rle_to_mask(short, dev).cpu().numpy()
+        for i in range(N):
+            n_enc = sum(short[i]["counts"])
+            ref = (masks[i].numpy() > 0).transpose().reshape(-1).copy()  # column-major order
+            ref[n_enc:] = False
+            assert np.array_equal(dec[i].astype(bool), ref.reshape(W, H).transpose())
+
+
+def test_mask_rle_rejects_cpu_and_bad_offsets(dev):
+    from sam6d_hip import _lib, ism
+    with pytest.raises(RuntimeError):
+        ism.mask_rle_encode(torch.zeros(1, 4, 4))
+    with pytest.raises(RuntimeError):
+        ism.rle_to_mask([{"counts": "abc", "size": [2, 2]}], dev)
+    m = torch.zeros(1, 4, 4, device=dev); m[0, 1, 1] = 1
+    counts = torch.full((8,), -5, dtype=torch.int32, device=dev)
+    offs = torch.tensor([0, 5], dtype=torch.int64, device=dev)  # the mask has 3 runs, not 5: nothing may be written
+    _lib.call("sam6d_mask_rle_encode", m.data_ptr(), 1, 4, 4, offs.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int((counts != -5).sum()) == 0
+
+
+def test_detection_ism_json_seam(dev, tmp_path):
+    """ISM/run_inference_custom.py:260-264: to_numpy -> save_to_file -> convert_npz_to_json -> save_json_bop23, then the PEM side
+    (run_inference_custom_pytorch.py:282-317): json.load -> per-instance RLE -> mask.  Records equal the oracle's; masks survive."""
+    import importlib
+    import json
+    import os
+    import sys
+    from oracle import ism_oracle as O
+    from sam6d_hip import ism
+    for k in [k for k in sys.modules if k == "model" or k.startswith("model.") or k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(PKG, "ism"))
+    U = importlib.import_module("model.utils")
+    g = torch.Generator().manual_seed(9)
+    N, H, W = 17, 120, 160
+    masks = (_blob_masks(g, N, H, W) > 0).float()
+    boxes = torch.randint(0, 100, (N, 4), generator=g)
+    scores = torch.rand(N, generator=g)
+    oids = torch.randint(0, 5, (N,), generator=g)
+    det = U.Detections({"masks": masks.to(dev), "boxes": boxes.to(dev)})
+    det.add_attribute("scores", scores.to(dev))
+    det.add_attribute("object_ids", oids.to(dev))
+    det.to_numpy()
+    path = str(tmp_path / "detection_ism")
+    det.save_to_file(0, 0, 0, path, "Custom", return_results=False)
+    recs = U.convert_npz_to_json(idx=0, list_npz_paths=[path + ".npz"])
+    U.save_json_bop23(path + ".json", recs)
+    want = O.detections_to_records(oids.numpy(), scores.numpy(), boxes.numpy(), masks.numpy())
+    assert recs == want
+    with open(path + ".json") as f:
+        loaded = json.load(f)
+    assert loaded == want
+    back = ism.rle_to_mask([r["segmentation"] for r in loaded], dev)
+    assert torch.equal(back.cpu(), masks.to(torch.uint8))
+    assert U.mask_to_rle(masks[3].numpy()) == want[3]["segmentation"]
+    again = U.Detections(path + ".npz")  # load_from_file: xywh -> xyxy, ids back to 0-based
+    assert np.array_equal(again.object_ids, oids.numpy()) and np.array_equal(np.asarray(again.masks), masks.numpy())

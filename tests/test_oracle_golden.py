@@ -328,3 +328,38 @@ def test_test_data_geometry_matches_reference_capture():
         sel = g["p%d_sel" % i]
         assert np.array_equal(o["cloud"][sel], g["p%d_pts" % i])
         assert np.array_equal(O.get_resize_rgb_choose(o["choose"][sel], o["bbox"], int(g["img_size"])), g["p%d_rgb_choose" % i])
+
+
+def test_mask_rle_oracle_matches_reference_capture_and_known_answers():
+    """detection_ism.json `segmentation` (ISM/model/utils.py:25-43, 199-216).  tests/golden/rle.npz holds the RLE the reference's
+    own segment_anything/utils/amg.py produced for seeded masks (same uncompressed COCO format; oracle/gen_golden.py:fx_rle)."""
+    g = golden("rle")
+    masks, counts, offs = g["masks"], g["counts"], g["offsets"]
+    for i in range(masks.shape[0]):
+        want = counts[offs[i]:offs[i + 1]].tolist()
+        got = IO.mask_to_rle(IO.force_binary_mask(masks[i].astype(np.float32)))
+        assert got == {"counts": want, "size": list(masks.shape[1:])}
+        if i in (0, 6, 7):
+            assert IO.mask_to_rle_loop(IO.force_binary_mask(masks[i])) == got
+        assert np.array_equal(IO.rle_to_mask(got), masks[i] > 0)
+    # hand-worked: 3 x 4 mask with (0,0) and (2,3) set -> column-major 1,0*10,1 -> leading zero run of length 0
+    m = np.zeros((3, 4)); m[0, 0] = 1; m[2, 3] = 1
+    assert IO.mask_to_rle(m)["counts"] == [0, 1, 10, 1] == IO.mask_to_rle_loop(m)["counts"]
+    assert IO.mask_to_rle(np.zeros((2, 5)))["counts"] == [10] and IO.mask_to_rle(np.ones((2, 5)))["counts"] == [0, 10]
+    # soft masks go through force_binary_mask (> 0), column-major order: [[0.2, 0], [0, -1]] -> 1,0,0,0
+    assert IO.mask_to_rle(IO.force_binary_mask(np.array([[0.2, 0.0], [0.0, -1.0]])))["counts"] == [0, 1, 3]
+
+
+def test_detection_records_format():
+    """save_to_file + convert_npz_to_json (ISM/model/utils.py:153-173, 199-216): key order, xywh without +1, category_id = id + 1
+    (LM-O: table), python scalars."""
+    import json
+    masks = np.zeros((2, 4, 6), np.float32); masks[0, 1:3, 2:5] = 1; masks[1, 0, 0] = 0.5
+    rec = IO.detections_to_records(np.array([0, 3]), np.array([0.75, 0.5], np.float32), np.array([[2, 1, 5, 3], [0, 0, 1, 1]]), masks,
+                                   scene_id=0, frame_id=0, runtime=0)
+    assert list(rec[0].keys()) == ["scene_id", "image_id", "category_id", "bbox", "score", "time", "segmentation"]
+    assert rec[0]["category_id"] == 1 and rec[1]["category_id"] == 4 and rec[0]["bbox"] == [2, 1, 3, 2]
+    assert rec[0]["segmentation"] == {"counts": [9, 2, 2, 2, 2, 2, 5], "size": [4, 6]} and rec[1]["segmentation"]["counts"] == [0, 1, 23]
+    assert json.loads(json.dumps(rec)) == rec
+    lmo = IO.detections_to_records(np.array([1, 7]), np.array([0.1, 0.2]), np.array([[0, 0, 1, 1], [0, 0, 1, 1]]), masks, dataset_name="lmo")
+    assert [r["category_id"] for r in lmo] == [5, 12]
