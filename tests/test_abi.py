@@ -86,3 +86,16 @@ def test_no_packed_fp32_math_in_device_code(tmp_path):
         n_mfma += len(re.findall(r"\bv_mfma_", asm))
         n_obj += 1
     assert n_obj >= 5 and n_mfma > 0, "disassembly looks empty (%d code objects, %d MFMA)" % (n_obj, n_mfma)
+
+
+def test_header_is_plain_c_and_the_c_consumer_builds():
+    """include/sam6d_hip.h compiles as C99 with gcc and links against the library: tests/cabi/cabi_check.c is a consumer with no
+    Python or torch in it (it runs on the GPU box: tests/test_cabi_c_gpu.py)."""
+    import subprocess
+    from sam6d_hip import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cabi"), "-s", "-B"])
+    assert os.path.exists(os.path.join(ROOT, "tests", "cabi", "cabi_check"))
+    src = open(os.path.join(ROOT, "tests", "cabi", "cabi_check.c")).read()
+    assert "Python.h" not in src and "torch" not in src.replace("no torch", "")
