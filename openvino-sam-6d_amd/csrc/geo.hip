@@ -392,18 +392,56 @@ extern "C" int sam6d_geo_embed_h3(const float* idx_ws, long pairs, const float* 
 // zeroes the list counter (a kernel rather than hipMemsetAsync: one launch path for everything on the stream)
 __global__ void geo_list_reset_kernel(int* __restrict__ list) { list[0] = 0; }
 
+// One workgroup classifies GCL_PER = 4096 pairs and reserves its list slots with ONE atomic (every out-of-range pair doing its own
+// atomicAdd on the single counter serialised ~13 000 atomics: 150 us for a 10 us pass; the bg token alone puts an out-of-range
+// pair into every 197-pair row).  The order of the list entries is arbitrary; consumers address rows through pos[].
+#define GCL_PPT 16
+#define GCL_PER (256 * GCL_PPT)
 __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax,
                                                            int* __restrict__ pos, int* __restrict__ list) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const float4 v = idx4[e];
-  const bool ok = v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f && v.w <= xmax;
-  int p = -1;
-  if (!ok) {
-    p = atomicAdd(list, 1);
-    list[1 + p] = (int)e;
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long e0 = (long)blockIdx.x * GCL_PER + t;
+  unsigned int out_mask = 0u;
+#pragma unroll
+  for (int i = 0; i < GCL_PPT; ++i) {
+    const long e = e0 + (long)i * 256;
+    if (e < total) {
+      const float4 v = idx4[e];
+      const bool ok = v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f && v.w <= xmax;
+      if (!ok) out_mask |= 1u << i;
+    }
   }
-  pos[e] = p;
+  const int cnt = __popc(out_mask);
+  int incl = cnt;  // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (t == 0) {
+    const int all = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = all > 0 ? atomicAdd(list, all) : 0;
+  }
+  __syncthreads();
+  int p = s_base + (incl - cnt);
+  for (int w = 0; w < wave; ++w) p += s_wave[w];
+#pragma unroll
+  for (int i = 0; i < GCL_PPT; ++i) {
+    const long e = e0 + (long)i * 256;
+    if (e < total) {
+      if ((out_mask >> i) & 1u) {
+        list[1 + p] = (int)e;
+        pos[e] = p;
+        ++p;
+      } else {
+        pos[e] = -1;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------- 3c. embedding, Chebyshev basis
@@ -563,7 +601,7 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
-  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb(classify)");
   const long ntiles = (pairs + GH_P - 1) / GH_P;
@@ -591,7 +629,7 @@ extern "C" int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, c
   if (int rc = h3_reserve_lds()) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
-  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_outliers(classify)");
   // rows of the listed pairs, bias-free, compact.  The grid covers the worst case (every pair listed); workgroups beyond
