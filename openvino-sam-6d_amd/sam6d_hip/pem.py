@@ -680,12 +680,27 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() == 1
     fused = fused and not return_aux
 
-    def prepare(lo, hi):
-        """FPS, gathers and the geometric indices of proposals [lo, hi): always on the caller's stream, never beside other
-        kernels (DESIGN "Concurrency caveat")."""
+    overlap = cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1")
+
+    def fork_fine_static(dp, df, side_key):
+        """The pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) on a second HIP
+        stream; the caller joins it (cur.wait_stream(side)) before the fine transformer."""
+        cur = torch.cuda.current_stream()
+        side = _side_stream(dp.device, side_key)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            D = fine_static(dp, df, W, cfg)
+        D.record_stream(cur)
+        return D, side
+
+    def prepare(lo, hi, side_key=None):
+        """FPS, gathers and the geometric indices of proposals [lo, hi) on the caller's stream.  With side_key (the default,
+        single-slice pipeline) the fine stage's static part is forked first, so that it fills the chip while FPS (one workgroup
+        per cloud, 196 sequential rounds) and the index kernels run; the micro-batch mode keeps this phase serial."""
         b = hi - lo
         dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
         df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
+        early = fork_fine_static(dp, df, side_key) if (side_key is not None and overlap) else None
         n = cfg["coarse_npoint"]
         sp, sf, idx = sample_pts_feats(dp, df, n)
         pb = _empty((2 * b, n + 1, 3), dp)
@@ -694,26 +709,22 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
             E = geo_context(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
         else:
             E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
-        return dp, df, sp, sf, idx, E
+        return dp, df, sp, sf, idx, E, early
 
     def rest(prep, lo, hi, side_key):
-        dp, df, sp, sf, idx, E = prep
+        dp, df, sp, sf, idx, E, early = prep
         rad, mod, rnd = radius[lo:hi].contiguous(), model[lo:hi].contiguous(), rand[lo:hi].contiguous()
         # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip
-        # idle; the pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) runs
-        # beside it on a second HIP stream and is joined before the fine transformer.
-        D = None
-        if cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1"):
-            cur = torch.cuda.current_stream()
-            side = _side_stream(dp.device, side_key)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                D = fine_static(dp, df, W, cfg)
-            D.record_stream(cur)
+        # idle; the static part of the fine stage runs beside it (forked here unless prepare already did).
+        D = side = None
+        if early is not None:
+            D, side = early
+        elif overlap:
+            D, side = fork_fine_static(dp, df, side_key)
         c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux)
         R0, t0 = c[0], c[1]
         if D is not None:
-            cur.wait_stream(side)
+            torch.cuda.current_stream().wait_stream(side)
         f = fine_point_matching(dp, df, E, idx, rad, mod, R0, t0, W, cfg, return_aux, D=D)
         if return_aux:
             b = hi - lo
@@ -723,7 +734,9 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
 
     dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
     if mb <= 1 or B < 8 * mb or return_aux:
-        return rest(prepare(0, B), 0, B, 0)
+        if _lib.load().sam6d_get_matmul_mode() == 1:
+            geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
+        return rest(prepare(0, B, side_key=0), 0, B, 0)
     main = torch.cuda.current_stream()
     if _lib.load().sam6d_get_matmul_mode() == 1:
         geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
