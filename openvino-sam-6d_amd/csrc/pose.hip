@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void sa_col_stats_part_kernel(const float* __r
   const int per = (R + SA_RS - 1) / SA_RS;
   const int r0 = rs * per, r1 = min(R, r0 + per);
   const float* a = att + (size_t)b * R * C + c;
+  // (unrolled: the strided loads of 8 rows are in flight together; the fp32 sum itself stays sequential in row order)
   float mx = -INFINITY;
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) mx = fmaxf(mx, a[(size_t)r * C]);
   float s = 0.f;
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) s += expf(a[(size_t)r * C] - mx);
   pmax[((size_t)b * SA_RS + rs) * C + c] = mx;
   psum[((size_t)b * SA_RS + rs) * C + c] = s;
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __
   const float* rsm = rsum + (size_t)b * R;
   float best = -INFINITY;
   int bi = 0x7fffffff;
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) {
     const float v = sa_value(a[(size_t)r * C], rm[r], rsm[r], cm, cs);
     if (v > best) {
@@ -222,33 +226,51 @@ extern "C" int sam6d_coarse_weights(const float* att, int B, int R, int C, const
 // SURVEY 8c n3); cum /= (cum[-1] + 1e-8); idx = first i with cum[i] >= u, 0 if none (model_utils.py:241-243,277-305).
 // One workgroup per row: each thread scans a contiguous chunk, chunk totals are scanned in LDS (double).
 // =========================================================================================================
+// Wave w owns the contiguous segment [w*seg, (w+1)*seg) of the row and walks it 64 elements at a time (coalesced loads): an
+// inclusive wave scan in double per step plus the carried sum.  Pass 1 yields the 16 segment totals, pass 2 repeats the same
+// arithmetic with the segment's offset as the initial carry, rounds to float, divides by the row total and stores.
+// (The previous form gave each thread a contiguous chunk: strided loads and a 1024-wide LDS scan with 20 barriers, 116 us.)
+__device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(v, o, 64);
+    if (lane >= o) v += up;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restrict__ w, int L, float* __restrict__ cum) {
-  __shared__ double part[1024];
-  __shared__ float s_total;
-  const int b = blockIdx.x, t = threadIdx.x;
+  __shared__ double s_tot[16];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* x = w + (size_t)b * L;
   float* o = cum + (size_t)b * L;
-  const int chunk = (L + 1023) / 1024;
-  const int i0 = t * chunk, i1 = min(L, i0 + chunk);
-  double acc = 0.0;
-  for (int i = i0; i < i1; ++i) acc += (double)x[i];
-  part[t] = acc;
-  __syncthreads();
-  for (int o2 = 1; o2 < 1024; o2 <<= 1) {  // inclusive Hillis-Steele scan
-    const double v = (t >= o2) ? part[t - o2] : 0.0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  const int steps = (L + 1023) / 1024;  // 64-element steps per wave
+  const int i0 = wave * steps * 64;
+  double carry = 0.0;
+#pragma unroll 4
+  for (int k = 0; k < steps; ++k) {
+    const int i = i0 + k * 64 + lane;
+    const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
+    carry += __shfl(inc, 63, 64);
   }
-  double run = (t == 0) ? 0.0 : part[t - 1];
-  for (int i = i0; i < i1; ++i) {
-    run += (double)x[i];
-    o[i] = (float)run;
-  }
-  if (i0 < L && i1 == L) s_total = (float)run;
+  if (lane == 0) s_tot[wave] = carry;
   __syncthreads();
-  const float den = s_total + 1e-8f;
-  for (int i = i0; i < i1; ++i) o[i] = o[i] / den;
+  double off = 0.0, total = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const double v = s_tot[q];
+    off += (q < wave) ? v : 0.0;
+    total += v;
+  }
+  const float den = (float)total + 1e-8f;
+  carry = off;
+#pragma unroll 4
+  for (int k = 0; k < steps; ++k) {
+    const int i = i0 + k * 64 + lane;
+    const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
+    if (i < L) o[i] = (float)(carry + inc) / den;
+    carry += __shfl(inc, 63, 64);
+  }
 }
 
 __global__ __launch_bounds__(256) void sample_first_ge_kernel(const float* __restrict__ cum, const float* __restrict__ u, int L,
@@ -420,27 +442,63 @@ extern "C" int sam6d_coarse_hypotheses(const int* idx, const float* pts1, const 
 
 // k smallest of each row by rank counting: rank_i = #{j : d_j < d_i or (d_j == d_i and j < i)}; sel[rank] = i.
 // Output is sorted ascending (torch.topk(largest=False) order; tie order there is unspecified).
+// A wave holds 64 consecutive candidates i0 .. i0+63: every j below i0 precedes all of them (count d_j <= d_i), every j from
+// i0+64 on follows all of them (count d_j < d_i); only the 64 j inside the wave's own range need the full tie rule.  Two VALU
+// instructions per (i, j) pair instead of six, four j per broadcast LDS read.
 __global__ __launch_bounds__(256) void select_smallest_kernel(const float* __restrict__ dis, int n, int k, int* __restrict__ sel) {
-  extern __shared__ float sd[];
+  extern __shared__ __attribute__((aligned(16))) float sd[];  // n floats, padded with +inf to a multiple of 4
   const int b = blockIdx.y;
   const float* d = dis + (size_t)b * n;
-  for (int i = threadIdx.x; i < n; i += 256) sd[i] = d[i];
+  const int n4 = (n + 3) & ~3;
+  for (int i = threadIdx.x; i < n4; i += 256) sd[i] = (i < n) ? d[i] : INFINITY;
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float v = sd[i];
-  int rank = 0;
-  for (int j = 0; j < n; ++j) {
+  const int i0 = i & ~63;  // first candidate of this wave (multiple of 64, so of 4)
+  if (i0 >= n) return;
+  const float v = (i < n) ? sd[i] : INFINITY;
+  // sign bit of (v - o) = [o > v], of (o - v) = [o < v]: one v_sub_f32 and one v_alignbit_b32 (shift the bit into a 32-bit
+  // register) per pair, one popcount per 32 pairs -- compare + conditional add costs three VALU slots plus wait states
+  auto signs4 = [](unsigned int acc, float a, const float4& q, bool q_minus_a) {
+    const float d0 = q_minus_a ? q.x - a : a - q.x, d1 = q_minus_a ? q.y - a : a - q.y;
+    const float d2 = q_minus_a ? q.z - a : a - q.z, d3 = q_minus_a ? q.w - a : a - q.w;
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d0), 31);
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d1), 31);
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d2), 31);
+    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d3), 31);
+    return acc;
+  };
+  int gt_before = 0;  // #{j < i0 : d_j > v}; the j below the wave's range that count are the other i0 - gt_before
+  for (int j = 0; j < i0; j += 32) {
+    unsigned int acc = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = signs4(acc, v, *reinterpret_cast<const float4*>(&sd[j + 4 * u]), false);
+    gt_before += __popc(acc);
+  }
+  int rank = i0 - gt_before;
+  const int i1 = min(i0 + 64, n4);
+  for (int j = i0; j < i1; ++j) {
     const float o = sd[j];
     rank += (o < v || (o == v && j < i)) ? 1 : 0;
   }
-  if (rank < k) sel[(size_t)b * k + rank] = i;
+  int j = i1;
+  for (; j + 32 <= n4; j += 32) {
+    unsigned int acc = 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = signs4(acc, v, *reinterpret_cast<const float4*>(&sd[j + 4 * u]), true);
+    rank += __popc(acc);
+  }
+  for (; j < n4; j += 4) {  // the +inf padding never counts: inf - v is +inf
+    const float4 o = *reinterpret_cast<const float4*>(&sd[j]);
+    rank += (o.x < v) + (o.y < v) + (o.z < v) + (o.w < v);
+  }
+  if (i < n && rank < k) sel[(size_t)b * k + rank] = i;
 }
 
 extern "C" int sam6d_select_smallest(const float* dis, int B, int n, int k, int* sel, void* stream) {
   SAM6D_REQUIRE(dis && sel && B >= 0 && n > 0 && k > 0 && k <= n && n <= 15000 && B <= 65535, "select_smallest: bad arguments (n <= 15000)");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)n * 4, (hipStream_t)stream, dis, n, k, sel);
+  hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)((n + 3) & ~3) * 4, (hipStream_t)stream, dis, n, k,
+                     sel);
   SAM6D_LAUNCH_CHECK("select_smallest");
 }
 

@@ -342,6 +342,50 @@ def test_select_smallest_matches_topk_set(dev):
     assert all(len(set(r.tolist())) == 300 for r in s)
 
 
+@pytest.mark.parametrize("B,n,k", [(3, 6000, 300), (2, 6001, 6001), (1, 37, 5), (2, 4099, 64), (1, 64, 64), (1, 1, 1)])
+def test_select_smallest_is_the_stable_rank_order(dev, B, n, k):
+    """sel[b, r] = the element with rank r under (value, index) order -- a stable ascending argsort, including exact ties, sizes
+    that are not multiples of the wave / the 32-pair popcount group, zeros and negative zeros."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(n + k)
+    d = torch.rand(B, n, generator=gen)
+    d[:, ::7] = d[:, 0:1].clone()  # many exact ties
+    if n > 40:
+        d[0, 10:20] = 0.0
+        d[0, 20:30] = -0.0        # -0 == +0: ties broken by index
+    sel = torch.full((B, k), -1, dtype=torch.int32, device=dev)
+    dd = d.to(dev)
+    _lib.call("sam6d_select_smallest", dd.data_ptr(), B, n, k, sel.data_ptr(), pem._s())
+    torch.cuda.synchronize()
+    want = torch.sort(d, dim=1, stable=True)[1][:, :k].to(torch.int32)
+    assert torch.equal(sel.cpu(), want)
+
+
+def test_cumsum_norm_and_sampling_vs_float64(dev):
+    """sam6d_weighted_sample: cum = cumsum in double rounded to float, / (cum[-1] + 1e-8); idx = first cum >= u (model_utils.py
+    :241-243, 277-305) at the path's row length (196 x 196) and at ragged lengths."""
+    from sam6d_hip import _lib, pem
+    for B, L, ns in ((3, 38416, 18000), (2, 1000, 50), (1, 70001, 300), (2, 64, 7)):
+        gen = torch.Generator().manual_seed(L)
+        w = torch.rand(B, L, generator=gen) ** 4
+        w[:, ::3] = 0
+        u = torch.rand(B, ns, generator=gen)
+        cum = torch.empty(B, L, device=dev)
+        idx = torch.empty(B, ns, dtype=torch.int32, device=dev)
+        wd, ud = w.to(dev), u.to(dev)
+        _lib.call("sam6d_weighted_sample", wd.data_ptr(), ud.data_ptr(), B, L, ns, cum.data_ptr(), idx.data_ptr(), pem._s())
+        torch.cuda.synchronize()
+        c64 = torch.cumsum(w.double(), 1).float()
+        want = c64 / (c64[:, -1:] + 1e-8)
+        got = cum.cpu()
+        assert float((got - want).abs().max()) <= 1.2e-7, (L, float((got - want).abs().max()))
+        assert (got[:, 1:] >= got[:, :-1]).all()
+        # the index search is checked on the kernel's own cum (a 1-ulp difference to the float64 recipe may move a boundary)
+        widx = torch.searchsorted(got, u, right=False)
+        widx = torch.where(widx >= L, torch.zeros_like(widx), widx)
+        assert torch.equal(idx.cpu().long(), widx)
+
+
 def _kat_atten(p1, p2, sharp, bg):
     B, n, _ = p1.shape
     d = torch.cdist(p1, p2)
