@@ -13,17 +13,34 @@
 // Soft assignment  S = softmax(att, dim=2) * softmax(att, dim=1)   (model_utils.py:229-233, 320-324)
 // att (B, R, C), row 0 / column 0 = background token.
 // =========================================================================================================
+#define SA_RPL 36
 __global__ __launch_bounds__(256) void sa_row_stats_kernel(const float* __restrict__ att, int C, long rows,
                                                            float* __restrict__ rmax, float* __restrict__ rsum) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* a = att + row * C;
-  float mx = -INFINITY;
-  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, a[c]);
-  mx = wave_max(mx);
-  float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += expf(a[c] - mx);
+  float mx = -INFINITY, s = 0.f;
+  if (C <= 64 * SA_RPL) {
+    // the row (<= 2304 floats) is read ONCE into registers, all loads in flight together; max and sum-exp then run from
+    // registers in the same per-lane order as the two-loop form below (identical bits)
+    float v[SA_RPL];
+#pragma unroll
+    for (int k = 0; k < SA_RPL; ++k) {
+      const int c = lane + 64 * k;
+      v[k] = (c < C) ? a[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < SA_RPL; ++k) mx = fmaxf(mx, v[k]);
+    mx = wave_max(mx);
+#pragma unroll
+    for (int k = 0; k < SA_RPL; ++k)
+      if (lane + 64 * k < C) s += expf(v[k] - mx);
+  } else {
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, a[c]);
+    mx = wave_max(mx);
+    for (int c = lane; c < C; c += 64) s += expf(a[c] - mx);
+  }
   s = wave_sum(s);
   if (lane == 0) {
     rmax[row] = mx;
@@ -542,6 +559,12 @@ __global__ __launch_bounds__(256) void score_hyp_kernel(const int* __restrict__ 
     const float x1 = fmaf(d2, R[7], fmaf(d1, R[4], d0 * R[1]));
     const float x2 = fmaf(d2, R[8], fmaf(d1, R[5], d0 * R[2]));
     const float sx = sqnorm3(x0, x1, x2);
+    // min over the CAD points of pdist3, six VALU instructions per pair instead of eight, same bits: 2*xy is exact, so
+    // sx - 2*xy = fma(-2, xy, sx); and min_m max(d_m, 0) = max(min_m d_m, 0), so the clamp moves out of the loop
+    auto raw = [&](float qx, float qy, float qz, float qw) {
+      const float xy = fmaf(x2, qz, fmaf(x1, qy, x0 * qx));
+      return fmaf(-2.0f, xy, sx) + qw;
+    };
     float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mn3 = INFINITY;
     int m = 0;
     for (; m + 4 <= P; m += 4) {
@@ -549,16 +572,17 @@ __global__ __launch_bounds__(256) void score_hyp_kernel(const int* __restrict__ 
       const float4 q1 = *reinterpret_cast<const float4*>(&sm[m * 4 + 4]);
       const float4 q2 = *reinterpret_cast<const float4*>(&sm[m * 4 + 8]);
       const float4 q3 = *reinterpret_cast<const float4*>(&sm[m * 4 + 12]);
-      mn0 = fminf(mn0, pdist3(x0, x1, x2, sx, q0.x, q0.y, q0.z, q0.w));
-      mn1 = fminf(mn1, pdist3(x0, x1, x2, sx, q1.x, q1.y, q1.z, q1.w));
-      mn2 = fminf(mn2, pdist3(x0, x1, x2, sx, q2.x, q2.y, q2.z, q2.w));
-      mn3 = fminf(mn3, pdist3(x0, x1, x2, sx, q3.x, q3.y, q3.z, q3.w));
+      mn0 = fminf(mn0, raw(q0.x, q0.y, q0.z, q0.w));
+      mn1 = fminf(mn1, raw(q1.x, q1.y, q1.z, q1.w));
+      mn2 = fminf(mn2, raw(q2.x, q2.y, q2.z, q2.w));
+      mn3 = fminf(mn3, raw(q3.x, q3.y, q3.z, q3.w));
     }
     for (; m < P; ++m) {
       const float4 q = *reinterpret_cast<const float4*>(&sm[m * 4]);
-      mn0 = fminf(mn0, pdist3(x0, x1, x2, sx, q.x, q.y, q.z, q.w));
+      mn0 = fminf(mn0, raw(q.x, q.y, q.z, q.w));
     }
-    const float mn = fminf(fminf(mn0, mn1), fminf(mn2, mn3));
+    float mn = fminf(fminf(mn0, mn1), fminf(mn2, mn3));
+    mn = mn < 0.0f ? 0.0f : mn;
     const float wv = w1[(size_t)b * N1 + i];
 #pragma unroll
     for (int gg = 0; gg < SH_G; ++gg)

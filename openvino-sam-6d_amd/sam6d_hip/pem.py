@@ -478,24 +478,35 @@ def sparse_to_dense_transformer(D, E, fps_idx, T):
     return Dn
 
 
-def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32, ns2=64):
-    """dst[b, 1 + i, :] += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2)))   (PositionalEncoding,
-    PEM/model/fine_point_matching.py:102-144).  pts (B',N,3); dst rows addressed by (dst_off, batch stride dst_sb)."""
+def pe_group(pts, r1=0.1, r2=0.2, ns1=32, ns2=64):
+    """The two ball queries of PositionalEncoding (fine_point_matching.py:108-131; new_xyz = pts + 1e-8, :117) in one pass."""
     Bp, N, _ = pts.shape
-    feat = _empty((Bp * N, 2 * 128), pts)
-    q = _empty((Bp, N, 3), pts)  # new_xyz = pts + 1e-8 (fine_point_matching.py:117)
+    q = _empty((Bp, N, 3), pts)
     _lib.call("sam6d_add_scalar", _p(pts), 0.00000001, Bp * N * 3, _p(q), _s())
     idx12 = (_empty((Bp, N, ns1), pts, torch.int32), _empty((Bp, N, ns2), pts, torch.int32))
     _lib.call("sam6d_ball_query2", _p(q), _p(pts), Bp, N, N, float(r1), ns1, _p(idx12[0]), float(r2), ns2, _p(idx12[1]), _s())
-    for k, ns in enumerate((ns1, ns2)):
+    return idx12
+
+
+def pe_apply(pts, idx12, W, dst, dst_off, dst_sb):
+    """dst rows += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2))) for the groups of pe_group."""
+    Bp, N, _ = pts.shape
+    feat = _empty((Bp * N, 2 * 128), pts)
+    for k in range(2):
         idx = idx12[k]
         L = W.pe["mlp"][k]
-        _lib.call("sam6d_pe_mlp_max", _p(pts), _p(idx), Bp, N, ns, _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
+        _lib.call("sam6d_pe_mlp_max", _p(pts), _p(idx), Bp, N, idx.shape[2], _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
                   _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),
                   _p(feat), 2 * 128, k * 128, _s())
     m3 = W.pe["mlp3"]
     gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
          sC=dst_sb, sR=dst_sb)
+
+
+def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32, ns2=64):
+    """dst[b, 1 + i, :] += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2)))   (PositionalEncoding,
+    PEM/model/fine_point_matching.py:102-144).  pts (B',N,3); dst rows addressed by (dst_off, batch stride dst_sb)."""
+    pe_apply(pts, pe_group(pts, r1, r2, ns1, ns2), W, dst, dst_off, dst_sb)
 
 
 def feature_similarity(F, B, n, out_proj, temp):
@@ -617,16 +628,29 @@ def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=Fal
     return out
 
 
+def fine_static_a(dp, df, W, cfg):
+    """First half of fine_static: token buffer D with in_proj of both clouds + the template cloud's ball queries (ordinary
+    grids that share the chip well)."""
+    B = dp.shape[0] // 2
+    D = _tokens_with_bg(df, W.fine["in_proj"], W.fine["bg"])
+    grp = pe_group(dp[B:], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
+    return D, grp
+
+
+def fine_static_b(dp, D, grp, W):
+    """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run)."""
+    Bp, N, _ = dp.shape
+    B = Bp // 2
+    pe_apply(dp[B:], grp, W, D, B * (N + 1) * C + C, (N + 1) * C)
+    return D
+
+
 def fine_static(dp, df, W, cfg):
     """The part of FinePointMatching.forward that does not depend on the coarse pose: in_proj of both clouds' dense
     features into the token buffer D (2B,N+1,256) with the bg token, and the positional encoding of the TEMPLATE cloud
     (PEM/model/fine_point_matching.py:47-51).  pem_match issues it on a side stream, under the latency-bound coarse stage."""
-    Bp, N, _ = dp.shape
-    B = Bp // 2
-    D = _tokens_with_bg(df, W.fine["in_proj"], W.fine["bg"])
-    positional_encoding_add(dp[B:], W, D, B * (N + 1) * C + C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"],
-                            cfg["pe_nsample1"], cfg["pe_nsample2"])
-    return D
+    D, grp = fine_static_a(dp, df, W, cfg)
+    return fine_static_b(dp, D, grp, W)
 
 
 def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None):
@@ -695,12 +719,20 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
 
     def prepare(lo, hi, side_key=None):
         """FPS, gathers and the geometric indices of proposals [lo, hi) on the caller's stream.  With side_key (the default,
-        single-slice pipeline) the fine stage's static part is forked first, so that it fills the chip while FPS (one workgroup
-        per cloud, 196 sequential rounds) and the index kernels run; the micro-batch mode keeps this phase serial."""
+        single-slice pipeline) the first half of the fine stage's static part (in_proj GEMM, ball queries) is forked BEFORE
+        these kernels and fills the chip while FPS (one workgroup per cloud, 196 sequential rounds) runs; its second half (the
+        persistent PE-MLP workgroups, which would keep the LDS-heavy outlier-embedding kernels of this phase waiting) is queued
+        behind an event recorded after them.  The micro-batch mode keeps this phase serial."""
         b = hi - lo
         dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
         df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
-        early = fork_fine_static(dp, df, side_key) if (side_key is not None and overlap) else None
+        early = None
+        if side_key is not None and overlap:
+            cur = torch.cuda.current_stream()
+            side = _side_stream(dp.device, side_key)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                D, grp = fine_static_a(dp, df, W, cfg)
         n = cfg["coarse_npoint"]
         sp, sf, idx = sample_pts_feats(dp, df, n)
         pb = _empty((2 * b, n + 1, 3), dp)
@@ -709,6 +741,16 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
             E = geo_context(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
         else:
             E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+        if side_key is not None and overlap:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                D = fine_static_b(dp, D, grp, W)
+            D.record_stream(cur)
+            for g_ in grp:
+                g_.record_stream(side)
+            early = (D, side)
         return dp, df, sp, sf, idx, E, early
 
     def rest(prep, lo, hi, side_key):
