@@ -99,8 +99,18 @@ __global__ __launch_bounds__(256) void sa_col_stats_merge_kernel(const float* __
 __device__ __forceinline__ float sa_value(float a, float rm, float rs, float cm, float cs) {
   return (expf(a - rm) / rs) * (expf(a - cm) / cs);
 }
+// The same product with the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32: ~1e-6 relative) -- 10 VALU
+// instructions instead of ~45.  Used for the LARGE (fine-stage, 2049 x 2049) matrices only, where the label / assignment
+// passes were bound by this arithmetic rather than by the 537 MB they stream; the 197 x 197 coarse matrix keeps the exact
+// form (its weights feed the hypothesis sampling, which is pinned index for index against the reference).
+template <bool FAST>
+__device__ __forceinline__ float sa_val(float a, float rm, float rs, float cm, float cs) {
+  if (FAST) return (__expf(a - rm) * __frcp_rn(rs)) * (__expf(a - cm) * __frcp_rn(cs));
+  return sa_value(a, rm, rs, cm, cs);
+}
 
 // label1[b, r-1] = argmax_c S[b, r, c] (first maximum), r = 1..R-1  -- one wave per row
+template <bool FAST>
 __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restrict__ att, int R, int C, long rows,
                                                             const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                             const float* __restrict__ cmax, const float* __restrict__ csum,
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restr
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int c = lane; c < C; c += 64) {
-    const float v = sa_value(a[c], rm, rs, cm[c], cs[c]);
+    const float v = sa_val<FAST>(a[c], rm, rs, cm[c], cs[c]);
     if (v > best) {
       best = v;
       bi = c;
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restr
 
 // label2[b, c-1] = argmax_r S[b, r, c] (first maximum), c = 1..C-1: row-sliced like the column statistics; the merge
 // keeps the lowest row on ties, so the result equals the sequential scan's.
+template <bool FAST>
 __global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __restrict__ att, int R, int C, int SA_RS,
                                                                  const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                                  const float* __restrict__ cmax, const float* __restrict__ csum,
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void sa_col_labels_part_kernel(const float* __
   int bi = 0x7fffffff;
 #pragma unroll 8
   for (int r = r0; r < r1; ++r) {
-    const float v = sa_value(a[(size_t)r * C], rm[r], rsm[r], cm, cs);
+    const float v = sa_val<FAST>(a[(size_t)r * C], rm[r], rsm[r], cm, cs);
     if (v > best) {
       best = v;
       bi = r;
@@ -196,10 +207,17 @@ extern "C" int sam6d_soft_assign(const float* att, int B, int R, int C, float* r
   hipLaunchKernelGGL(sa_col_stats_part_kernel, dim3(cdiv(C, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, p0, p1);
   hipLaunchKernelGGL(sa_col_stats_merge_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, s, p0, p1, C, SA_RS, cmax, csum);
   const long lrows = (long)B * (R - 1);
-  hipLaunchKernelGGL(sa_row_labels_kernel, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
-                     cmax, csum, label1);
-  hipLaunchKernelGGL(sa_col_labels_part_kernel, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, rmax, rsum,
-                     cmax, csum, p0, reinterpret_cast<int*>(p1));
+  if (R > 256) {  // fine-stage sizes: hardware exp / rcp (see sa_val)
+    hipLaunchKernelGGL(sa_row_labels_kernel<true>, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
+                       cmax, csum, label1);
+    hipLaunchKernelGGL(sa_col_labels_part_kernel<true>, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, rmax,
+                       rsum, cmax, csum, p0, reinterpret_cast<int*>(p1));
+  } else {
+    hipLaunchKernelGGL(sa_row_labels_kernel<false>, dim3((unsigned)((lrows + 3) / 4)), dim3(256), 0, s, att, R, C, lrows, rmax, rsum,
+                       cmax, csum, label1);
+    hipLaunchKernelGGL(sa_col_labels_part_kernel<false>, dim3(cdiv(C - 1, 256), B, SA_RS), dim3(256), 0, s, att, R, C, SA_RS, rmax,
+                       rsum, cmax, csum, p0, reinterpret_cast<int*>(p1));
+  }
   hipLaunchKernelGGL(sa_col_labels_merge_kernel, dim3(cdiv(C - 1, 256), B), dim3(256), 0, s, p0, reinterpret_cast<const int*>(p1),
                      C, SA_RS, label2);
   SAM6D_LAUNCH_CHECK("soft_assign");
@@ -648,6 +666,7 @@ extern "C" int sam6d_score_select_hypotheses(const int* sel, const float* Rs, co
 // Fine pose (model_utils.py:308-341)
 // =========================================================================================================
 // per row r >= 1:  A[r,c] = S[r,c] * [l1>0] * [l2>0]  (c >= 1);  weight = sum_c A;  pred = sum_c (A / (weight + 1e-6)) p2[c-1]
+template <bool FAST>
 __global__ __launch_bounds__(256) void fine_assign_kernel(const float* __restrict__ att, int R, int C, long rows,
                                                           const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                           const float* __restrict__ cmax, const float* __restrict__ csum,
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(256) void fine_assign_kernel(const float* __restric
   const float f1 = label1[w] > 0 ? 1.f : 0.f;
   float sa = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
   for (int c = 1 + lane; c < C; c += 64) {
-    float v = sa_value(a[c], rm, rs, cm[c], cs[c]);
+    float v = sa_val<FAST>(a[c], rm, rs, cm[c], cs[c]);
     v = (v * f1) * (l2[c - 1] > 0 ? 1.f : 0.f);
     sa += v;
     sx = fmaf(v, p2[(c - 1) * 3], sx);
@@ -691,8 +710,12 @@ extern "C" int sam6d_fine_assign(const float* att, int B, int R, int C, const fl
   SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && pts2 && pred && weight, "fine_assign: null pointer");
   const long rows = (long)B * (R - 1);
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(fine_assign_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, R, C, rows, rmax,
-                     rsum, cmax, csum, label1, label2, pts2, pred, weight);
+  if (R > 256)
+    hipLaunchKernelGGL(fine_assign_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, R, C, rows,
+                       rmax, rsum, cmax, csum, label1, label2, pts2, pred, weight);
+  else
+    hipLaunchKernelGGL(fine_assign_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, att, R, C, rows,
+                       rmax, rsum, cmax, csum, label1, label2, pts2, pred, weight);
   SAM6D_LAUNCH_CHECK("fine_assign");
 }
 
