@@ -614,14 +614,17 @@ def _tokens_with_bg(x, lin, bg, extra=None):
     return T
 
 
-def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=False):
-    """sp (2B,n,3), sf (2B,n,256) stacked [scene; template]  (PEM/model/coarse_point_matching.py:32-63, eval)."""
+def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=False, before_pose=None):
+    """sp (2B,n,3), sf (2B,n,256) stacked [scene; template]  (PEM/model/coarse_point_matching.py:32-63, eval).
+    before_pose: optional callable run between the transformer and the pose solver (pem_match queues side-stream work there)."""
     B = sp.shape[0] // 2
     n = sp.shape[1]
     S = _tokens_with_bg(sf, W.coarse["in_proj"], W.coarse["bg"])
     for blk in W.coarse["blocks"]:
         S = geometric_transformer(S, E, blk)
     att = feature_similarity(S, B, n + 1, W.coarse["out_proj"], cfg["temp"])
+    if before_pose is not None:
+        before_pose()
     out = compute_coarse_Rt(att, sp[:B], sp[B:], model, radius, rand, cfg["nproposal1"], cfg["nproposal2"], return_aux)
     if return_aux:
         out[2]["atten"] = att
@@ -722,7 +725,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         single-slice pipeline) the first half of the fine stage's static part (in_proj GEMM, ball queries) is forked BEFORE
         these kernels and fills the chip while FPS (one workgroup per cloud, 196 sequential rounds) runs; its second half (the
         persistent PE-MLP workgroups, which would keep the LDS-heavy outlier-embedding kernels of this phase waiting) is queued
-        behind an event recorded after them.  The micro-batch mode keeps this phase serial."""
+        by rest() beside the coarse pose solver.  The micro-batch mode keeps this phase serial."""
         b = hi - lo
         dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
         df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
@@ -742,15 +745,8 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         else:
             E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
         if side_key is not None and overlap:
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                D = fine_static_b(dp, D, grp, W)
             D.record_stream(cur)
-            for g_ in grp:
-                g_.record_stream(side)
-            early = (D, side)
+            early = (D, side, grp)
         return dp, df, sp, sf, idx, E, early
 
     def rest(prep, lo, hi, side_key):
@@ -759,11 +755,23 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip
         # idle; the static part of the fine stage runs beside it (forked here unless prepare already did).
         D = side = None
+        hook = None
         if early is not None:
-            D, side = early
+            D, side, grp = early
+
+            def hook():
+                # second half of the static fine work: the PE MLPs are matrix-pipe work, the pose solver that starts here
+                # (soft assignment, sampling, 6000 SVDs, hypothesis scoring) is VALU / latency work -- they share the chip well,
+                # and the RPE score kernels of the transformer above keep the matrix pipe to themselves
+                cur = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    fine_static_b(dp, D, grp, W)
         elif overlap:
             D, side = fork_fine_static(dp, df, side_key)
-        c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux)
+        c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux, before_pose=hook)
         R0, t0 = c[0], c[1]
         if D is not None:
             torch.cuda.current_stream().wait_stream(side)
