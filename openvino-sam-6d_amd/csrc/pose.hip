@@ -282,7 +282,6 @@ __global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restri
   const int steps = (L + 1023) / 1024;  // 64-element steps per wave
   const int i0 = wave * steps * 64;
   double carry = 0.0;
-#pragma unroll 4
   for (int k = 0; k < steps; ++k) {
     const int i = i0 + k * 64 + lane;
     const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
@@ -299,7 +298,6 @@ __global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restri
   }
   const float den = (float)total + 1e-8f;
   carry = off;
-#pragma unroll 4
   for (int k = 0; k < steps; ++k) {
     const int i = i0 + k * 64 + lane;
     const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
