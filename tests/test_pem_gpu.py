@@ -618,7 +618,8 @@ def test_pem_match_fused_vs_materialised(dev, W):
 
 def test_pem_match_repeatable_with_side_stream(dev, W):
     """The default pipeline (one batch, pose-independent fine work on a side stream) must reproduce the serial result bit for
-    bit, run after run.  (The experimental micro-batch mode does not yet: see pem.pem_match.)"""
+    bit, run after run (the micro-batch mode has its own invariance test; both have been bit-stable since the library is built
+    without packed-fp32 instructions, DESIGN "Concurrency caveat")."""
     from sam6d_hip import pem, synth
     inp = synth.config2_inputs(B=16, seed=5)
     d = {k: v.to(dev).contiguous() for k, v in inp.items()}
@@ -628,6 +629,21 @@ def test_pem_match_repeatable_with_side_stream(dev, W):
     for rep in range(12):
         for a, b, what in zip(run(True), ref, ("R", "t", "score")):
             assert torch.equal(a, b), "run %d with the side stream: %s differs by %.3e" % (rep, what, float((a - b).abs().max()))
+
+
+def test_pem_match_microbatch_mode_is_bit_invariant(dev, W):
+    """SAM6D_MICROBATCH=2 (two slices on two HIP streams, off by default) returns the serial result bit for bit: the slices are
+    independent proposals and no kernel's arithmetic depends on the batch size.  (Before the library was built without packed-fp32
+    instructions a third of such runs differed: DESIGN "Concurrency caveat"; scratch/dbg_ov.py is the long stress.)"""
+    from sam6d_hip import pem, synth
+    inp = synth.config2_inputs(B=16, seed=6)
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    run = lambda mb: [o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
+                                                     d["model"], W, d["rand"], cfg=dict(pem.DEFAULT_CFG, overlap=True, microbatch=mb))]
+    ref = run(1)
+    for rep in range(6):
+        for a, b, what in zip(run(2), ref, ("R", "t", "score")):
+            assert torch.equal(a, b), "run %d with two slices: %s differs by %.3e" % (rep, what, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("M,K", [(1, 256), (197, 256), (6304, 512), (65, 32), (4099, 256)])
