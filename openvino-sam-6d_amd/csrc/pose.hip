@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void score_hyp_kernel(const int* __restrict__ 
                                                         const float* __restrict__ w1, const float* __restrict__ model,
                                                         const float* __restrict__ radius, int N1, int P, int nh, int k,
                                                         float* __restrict__ scores) {
-  extern __shared__ float sm[];  // [P*4]: x,y,z,|m|^2
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [P*4]: x,y,z,|m|^2
   __shared__ float sRt[SH_G][12];
   __shared__ float red[2][SH_G][4];
   const int b = blockIdx.y, s0 = blockIdx.x * SH_G, t = threadIdx.x;
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void fine_near_kernel(const float* __restrict_
                                                         const float* __restrict__ t, const float* __restrict__ model,
                                                         const float* __restrict__ radius, const int* __restrict__ label1, int N,
                                                         int P, float thr, float* __restrict__ cnt) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ float red[2][4];
   const int b = blockIdx.y, tid = threadIdx.x;
   const float den = radius[b] + 1e-6f;
