@@ -124,10 +124,13 @@ __global__ __launch_bounds__(256) void attention_mq_kernel(const float* __restri
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) qv[qi] = *reinterpret_cast<const float4*>(qrow0 + (size_t)min(i0 + qi, n - 1) * ldq + lane * 4);
   const float* kb = k + (size_t)b * sk;
-  for (int j0 = wave * 4; j0 < m; j0 += 16) {
-    float4 kv[4];
+  // (the k rows of the next step are requested before this step's dot products: the loop is bound by L2 latency, not by VALU)
+  float4 kv[4], kn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)min(j0 + u, m - 1) * ldk + lane * 4);
+  for (int u = 0; u < 4; ++u) kv[u] = *reinterpret_cast<const float4*>(kb + (size_t)min(wave * 4 + u, m - 1) * ldk + lane * 4);
+  for (int j0 = wave * 4; j0 < m; j0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kn[u] = *reinterpret_cast<const float4*>(kb + (size_t)min(j0 + 16 + u, m - 1) * ldk + lane * 4);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = j0 + u;
@@ -138,6 +141,8 @@ __global__ __launch_bounds__(256) void attention_mq_kernel(const float* __restri
         if ((lane & 15) == 0 && j < m) s_s[qi][lane >> 4][j] = sa * scale;
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kv[u] = kn[u];
   }
   __syncthreads();
 #pragma unroll
@@ -162,6 +167,19 @@ __global__ __launch_bounds__(256) void attention_mq_kernel(const float* __restri
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) acc[qi][0] = acc[qi][1] = 0.f;
   int j = 0;
+  for (; j + 8 <= m; j += 8) {  // eight v rows in flight; each accumulator sees its terms in the same order as in the 2-step loop
+    float vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vv[u] = vb[(size_t)(j + u) * ldv];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        acc[qi][0] = fmaf(s_s[qi][t >> 6][j + u], vv[u], acc[qi][0]);
+        acc[qi][1] = fmaf(s_s[qi][t >> 6][j + u + 1], vv[u + 1], acc[qi][1]);
+      }
+    }
+  }
   for (; j + 2 <= m; j += 2) {
     const float v0 = vb[(size_t)j * ldv], v1 = vb[(size_t)(j + 1) * ldv];
 #pragma unroll
