@@ -597,7 +597,11 @@ def fx_ism():
     close(oappe, appe, "ism appe", 1e-6)
     # masks / depth / intrinsics (Example camera: SAM-6D/Data/Example/camera.json)
     H, W = 480, 640
-    K = torch.tensor([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]])
+    # dtypes exactly as the reference's caller builds them (ISM/run_inference_custom.py:86-96 batch_input_data):
+    # cam_K = np.array(json list).reshape(3,3) -> float64; depth_scale = np.array(json float) -> float64 (1,); depth int32
+    K = torch.from_numpy(np.array(IO.EXAMPLE_CAM_K).reshape((3, 3)))
+    depth_scale = torch.from_numpy(np.array(1.0)).unsqueeze(0)
+    assert K.dtype == torch.float64 and depth_scale.dtype == torch.float64
     depth = (800 + 200 * torch.rand(H, W, generator=g)).to(torch.int32)
     depth[torch.rand(H, W, generator=g) < 0.1] = 0
     Ns = len(sel)
@@ -608,11 +612,14 @@ def fx_ism():
         w = int(torch.randint(40, 120, (1,), generator=g)); h = int(torch.randint(40, 120, (1,), generator=g))
         masks[i, y0:y0 + h, x0:x0 + w] = 1
         boxes[i] = torch.tensor([x0, y0, x0 + w, y0 + h])
-    batch = {"depth": depth[None], "cam_intrinsic": K[None], "depth_scale": torch.tensor([1.0])}
+    batch = {"depth": depth[None], "cam_intrinsic": K[None], "depth_scale": depth_scale}
     vu = m.project_template_to_image(best, obj, batch, masks.clone())
-    ovu = IO.project_template_to_image(best, obj, poses, pc, masks.clone(), depth, K, torch.tensor([1.0]))
+    tr = m.Calculate_the_query_translation(masks.clone(), depth, K, depth_scale)
+    ovu = IO.project_template_to_image(best, obj, poses, pc, masks.clone(), depth, K, depth_scale)
     same(ovu, vu, "ism vu")
+    same(IO.query_translation(masks.clone(), depth, K, depth_scale), tr, "ism translate")
     dets = Cfg(boxes=boxes)
+    xyxy = torch.concatenate((torch.min(vu, dim=1).values, torch.max(vu, dim=1).values), dim=-1)
     iou, vis = m.compute_geometric_score(vu, dets, qa, ref_sel, visible_thred=0.5)
     oiou, ovis = IO.geometric_score(vu, boxes, qa, oref, 0.5)
     close(ovis, vis, "ism vis", 1e-6)
@@ -621,13 +628,13 @@ def fx_ism():
     # the quirk branch (bbox_utils.py:214-220): ONE non-overlapping pair turns the whole result into scalar 0.0
     boxes_q = boxes.clone()
     boxes_q[3] = torch.tensor([0, 0, 2, 2])
-    xyxy = torch.concatenate((torch.min(vu, dim=1).values, torch.max(vu, dim=1).values), dim=-1)
     iou_q = bbox.compute_iou(xyxy, boxes_q)
     assert isinstance(iou_q, float) and iou_q == 0.0 and IO.compute_iou(xyxy, boxes_q) == 0.0
     fin = (sem + appe + iou * vis) / (1 + 1 + vis)
     close(IO.final_score(osem, oappe, oiou, ovis), fin, "ism final", 1e-6)
     save("ism", seed=0, sim_rows=sim[:8], sel=sel.to(torch.int32), obj=obj.to(torch.int32), sem=sem,
-         best=best.to(torch.int32), appe=appe, vis=vis, vu_sha=sha(vu), vu_head=vu[:4, :64],
+         best=best.to(torch.int32), appe=appe, vis=vis, vu_sha=sha(vu), vu=vu.to(torch.int16), translate=tr,
+         xyxy=xyxy.to(torch.int32),
          boxes=boxes.to(torch.int32), iou=iou, iou_quirk=np.float32(iou_q), final=fin)
 
 

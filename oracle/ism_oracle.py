@@ -10,6 +10,16 @@ import torch
 import torch.nn.functional as F
 
 
+# SAM-6D/Data/Example/camera.json (cam_K, depth_scale): the demo camera, used by the ISM fixtures
+EXAMPLE_CAM_K = [572.4114, 0.0, 325.2611, 0.0, 573.57043, 242.04899, 0.0, 0.0, 1.0]
+
+
+def caller_intrinsics(cam_K=EXAMPLE_CAM_K, depth_scale=1.0):
+    """K (3,3) and depth_scale (1,) with the dtypes the reference's caller hands to the model: np.array of the JSON
+    numbers -> float64 tensors (ISM/run_inference_custom.py:86-96, batch_input_data)."""
+    return torch.from_numpy(np.array(cam_K).reshape((3, 3))), torch.from_numpy(np.array(depth_scale)).unsqueeze(0)
+
+
 def pairwise_similarity(query, reference):
     """ISM/model/loss.py:27-44: cosine of every query (Nq,D) with every template (No,Nt,D) -> (Nq,No,Nt) in [0,1]."""
     Nq = query.shape[0]

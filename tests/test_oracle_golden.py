@@ -233,10 +233,11 @@ def ism_inputs(seed=0):
     poses[:, :3, 3] = torch.randn(Nt, 3, generator=gen) * 0.4
     pc = (torch.rand(1, 2048, 3, generator=gen) - 0.5) * 0.2
     H, W = 480, 640
-    K = torch.tensor([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]])
+    K, depth_scale = IO.caller_intrinsics()  # float64, as the reference's caller passes them
     depth = (800 + 200 * torch.rand(H, W, generator=gen)).to(torch.int32)
     depth[torch.rand(H, W, generator=gen) < 0.1] = 0
-    return dict(q=q, ref=ref, q_appe=q_appe, r_appe=r_appe, poses=poses, pc=pc, K=K, depth=depth, gen=gen, H=H, W=W)
+    return dict(q=q, ref=ref, q_appe=q_appe, r_appe=r_appe, poses=poses, pc=pc, K=K, depth_scale=depth_scale, depth=depth, gen=gen,
+                H=H, W=W)
 
 
 def ism_masks(gen, Ns, H=480, W=640):
@@ -265,8 +266,10 @@ def test_ism_scoring():
     np.testing.assert_allclose(appe.numpy(), g["appe"], atol=2e-6, rtol=0)
     masks, boxes = ism_masks(d["gen"], len(sel))
     assert np.array_equal(boxes.numpy().astype(np.int32), g["boxes"])
-    vu = IO.project_template_to_image(best, obj, d["poses"], d["pc"], masks, d["depth"], d["K"], torch.tensor([1.0]))
-    assert _sha(vu) == str(g["vu_sha"])
+    vu = IO.project_template_to_image(best, obj, d["poses"], d["pc"], masks, d["depth"], d["K"], d["depth_scale"])
+    assert _sha(vu) == str(g["vu_sha"]) and np.array_equal(vu.numpy(), g["vu"].astype(np.int32))
+    tr = IO.query_translation(masks, d["depth"], d["K"], d["depth_scale"])
+    assert tr.dtype == torch.float32 and np.array_equal(tr.numpy(), g["translate"])  # float64 inside, one rounding at the end
     iou, vis = IO.geometric_score(vu, boxes, qa, ref_sel, 0.5)
     np.testing.assert_allclose(vis.numpy(), g["vis"], atol=1e-6, rtol=0)
     np.testing.assert_allclose(iou.numpy(), g["iou"], atol=1e-6, rtol=0)
