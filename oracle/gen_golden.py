@@ -463,12 +463,11 @@ def fx_procrustes(ext, mods):
     save("procrustes", src=src, ref=ref, R=R, t=t, seed_w=22, Rw=Rw, tw=tw, w=w.half(), s2_sha=sha(s2))
 
 
-def fx_pem_e2e(ext, mods):
-    """Whole path at the post-feature-extraction seam (Net.forward:29-55 restated here) with the
-    reference's CoarsePointMatching / FinePointMatching / GeometricStructureEmbedding modules."""
+def ref_seam(mods, sd):
+    """The reference's GeometricStructureEmbedding / CoarsePointMatching / FinePointMatching modules loaded (strict) with `sd` and
+    driven at the post-feature-extraction seam: Net.forward:29-55 restated (pose_estimation_model.Net itself needs timm)."""
     T, C_, F_, MU = mods["transformer"], mods["coarse_point_matching"], mods["fine_point_matching"], mods["model_utils"]
     geo_cfg, ccfg, fcfg = ref_cfgs()
-    sd = synth.make_pem_weights(1)
     geo = T.GeometricStructureEmbedding(geo_cfg).eval()
     cpm = C_.CoarsePointMatching(ccfg).eval()
     fpm = F_.FinePointMatching(fcfg).eval()
@@ -493,6 +492,15 @@ def fx_pem_e2e(ext, mods):
             R, t, s = fpm(pm, fm, gm, im, po, fo, go, io_, radius, model, R0, t0)
         return R, t, s, R0, t0, im, io_
 
+    return ref_forward
+
+
+def fx_pem_e2e(ext, mods):
+    """Whole path at the post-feature-extraction seam (Net.forward:29-55 restated in ref_seam) with the
+    reference's CoarsePointMatching / FinePointMatching / GeometricStructureEmbedding modules."""
+    sd = synth.make_pem_weights(1)
+    ref_forward = ref_seam(mods, sd)
+
     out = {}
     for tag, inp in (("kat", synth.kat_inputs(B=2, seed=3)), ("cfg2", synth.config2_inputs(B=2, seed=1))):
         R, t, s, R0, t0, im, io_ = ref_forward(inp)
@@ -507,6 +515,120 @@ def fx_pem_e2e(ext, mods):
         out.update({tag + "_R": R, tag + "_t": t, tag + "_score": s, tag + "_R0": R0, tag + "_t0": t0,
                     tag + "_fps_m": im.to(torch.int16), tag + "_fps_o": io_.to(torch.int16)})
     save("pem_e2e", weights_seed=1, kat_seed=3, cfg2_seed=1, **out)
+
+
+def read_ply_ascii(path):
+    """Own reader for the ASCII PLY of the demo CAD model (vertex x y z ... / face `3 i j k`): returns (V,3) float64, (F,3) int64."""
+    with open(path, "rb") as f:
+        nv = nf = 0
+        while True:
+            line = f.readline().decode("ascii").strip()
+            if line.startswith("format"):
+                assert "ascii" in line, "binary PLY not handled"
+            if line.startswith("element vertex"):
+                nv = int(line.split()[-1])
+            if line.startswith("element face"):
+                nf = int(line.split()[-1])
+            if line == "end_header":
+                break
+        body = f.read().decode("ascii").split("\n")
+    V = np.array([[float(x) for x in body[i].split()[:3]] for i in range(nv)], np.float64)
+    Fc = np.array([[int(x) for x in body[nv + i].split()[1:4]] for i in range(nf)], np.int64)
+    return V, Fc
+
+
+def sample_surface(V, Fc, n, rs):
+    """Area-weighted uniform surface sample (what trimesh's mesh.sample does; trimesh is not installed, so own code + own seed)."""
+    a, b, c = V[Fc[:, 0]], V[Fc[:, 1]], V[Fc[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    f = rs.choice(len(Fc), size=n, p=area / area.sum())
+    u, v = rs.rand(n), rs.rand(n)
+    flip = u + v > 1
+    u[flip], v[flip] = 1 - u[flip], 1 - v[flip]
+    return a[f] + u[:, None] * (b[f] - a[f]) + v[:, None] * (c[f] - a[f])
+
+
+CONFIG1_SEED_PIXEL = (270, 405)  # (row, col) on the watering can (LM-O object 5) in SAM-6D/Data/Example/rgb.png
+
+
+def fx_config1(ext, mods):
+    """the demo Example (SAM-6D/Data/Example/{depth.png,camera.json,obj_000005.ply}), one proposal, 2048 points,
+    through the reference modules at the post-feature-extraction seam.  No ISM weights exist offline, so the proposal mask is the set of
+    pixels whose back-projected point lies within 1.2 x radius of the point at CONFIG1_SEED_PIXEL; the rest follows get_test_data
+    (PEM/run_inference_custom_pytorch.py:292-355: depth -> cloud, mask & depth>0, get_bbox, radius filter, 2048 random points) with the
+    reference's own helpers, and ViTEncoder.forward's radius normalisation (PEM/model/feature_extraction.py:133-137).  Features are
+    N(0,1) (seed 1) and the weights random-init (seed 1): the ViT backbone and its checkpoint are outside the path."""
+    import json
+    from PIL import Image
+    for name in ("imageio", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    du = importlib.import_module("data_utils")
+    MU = mods["model_utils"]
+    EX = "/root/reference/SAM-6D/Data/Example"
+    cam = json.load(open(os.path.join(EX, "camera.json")))
+    # K as float32: get_point_cloud_from_depth then computes in float32 under numpy 1.26 (the version the reference pins; value-based
+    # casting) and numpy 2.x alike
+    K = np.array(cam["cam_K"]).reshape(3, 3).astype(np.float32)
+    depth_u16 = np.array(Image.open(os.path.join(EX, "depth.png")))
+    assert depth_u16.dtype == np.uint16 and depth_u16.shape == (480, 640)
+    whole_depth = (depth_u16.astype(np.float32) * np.float32(cam["depth_scale"]) / np.float32(1000.0)).astype(np.float32)
+    whole_pts = du.get_point_cloud_from_depth(whole_depth, K)
+    assert whole_pts.dtype == np.float32
+    V, Fc = read_ply_ascii(os.path.join(EX, "obj_000005.ply"))
+    rs = np.random.RandomState(0)
+    model_points = (sample_surface(V, Fc, 1024, rs).astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+    tem_pts = (sample_surface(V, Fc, 5000, rs).astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+    radius = np.max(np.linalg.norm(model_points, axis=1))
+    r0, c0 = CONFIG1_SEED_PIXEL
+    assert whole_depth[r0, c0] > 0
+    seed_pt = whole_pts[r0, c0]
+    mask = np.linalg.norm(whole_pts - seed_pt[None, None, :], axis=2) < np.float32(np.float64(radius) * 1.2)
+    mask = np.logical_and(mask, whole_depth > 0)
+    assert np.sum(mask) > 32
+    bbox = du.get_bbox(mask)
+    y1, y2, x1, x2 = bbox
+    m = mask[y1:y2, x1:x2]
+    choose = m.astype(np.float32).flatten().nonzero()[0]
+    cloud = whole_pts.copy()[y1:y2, x1:x2, :].reshape(-1, 3)[choose, :]
+    center = np.mean(cloud, axis=0)
+    flag = np.linalg.norm(cloud - center[None, :], axis=1) < np.float32(np.float64(radius) * 1.2)  # `radius * 1.2` under numpy 1.26
+    assert np.sum(flag) >= 4
+    choose, cloud = choose[flag], cloud[flag]
+    rs1 = np.random.RandomState(1)
+    assert len(choose) > 2048
+    choose_idx = rs1.choice(np.arange(len(choose)), 2048, replace=False)
+    pts = cloud[choose_idx]
+    rgb_choose = du.get_resize_rgb_choose(choose[choose_idx], [y1, y2, x1, x2], 224)
+    # template side: 2048 FPS points of the 5000-point surface sample with N(0,1) features (sample_pts_feats, as get_obj_feats does)
+    g = gen(1)
+    tem_feat = torch.randn(1, 5000, 256, generator=g)
+    dense_fm = torch.randn(1, 2048, 256, generator=g)
+    rand = torch.rand(1, 18000, generator=g)
+    with torch.no_grad():
+        dense_po_raw, dense_fo, tem_idx = MU.sample_pts_feats(torch.from_numpy(tem_pts)[None], tem_feat, 2048, return_index=True)
+    # the caller `.repeat`s the template tensors per instance (run_inference_custom_pytorch.py:445-446), which makes them contiguous
+    dense_po_raw, dense_fo = dense_po_raw.repeat(1, 1, 1).contiguous(), dense_fo.repeat(1, 1, 1).contiguous()
+    # ViTEncoder.forward (feature_extraction.py:133-137)
+    pts_t = torch.from_numpy(pts)[None]
+    rad_t = torch.norm(dense_po_raw, dim=2).max(1)[0]
+    dense_pm = pts_t / (rad_t.reshape(-1, 1, 1) + 1e-6)
+    dense_po = dense_po_raw / (rad_t.reshape(-1, 1, 1) + 1e-6)
+    model_t = torch.from_numpy(model_points)[None]
+    sd = synth.make_pem_weights(1)
+    inp = dict(dense_pm=dense_pm, dense_fm=dense_fm, dense_po=dense_po, dense_fo=dense_fo, radius=rad_t, model=model_t, rand=rand)
+    R, t, sc, R0, t0, im, io_ = ref_seam(mods, sd)(inp)
+    oR, ot, os_, aux = O.pem_match(dense_pm, dense_fm, dense_po, dense_fo, rad_t, model_t, sd, rand, return_aux=True)
+    same(aux["fps_idx_m"], im, "config1 fps m"); same(aux["fps_idx_o"], io_, "config1 fps o")
+    print("   config1: %d masked px, %d kept, radius %.4f; oracle-vs-reference dR0 %.2e dt0 %.2e dR %.2e dt %.2e ds %.2e" % (
+        int(mask.sum()), len(choose), float(radius), (aux["init_R"] - R0).abs().max(), (aux["init_t"] - t0).abs().max(),
+        (oR - R).abs().max(), (ot - t).abs().max(), (os_ - sc).abs().max()))
+    save("config1", depth_u16=depth_u16, K=K, depth_scale=np.float32(cam["depth_scale"]), seed_pixel=np.array(CONFIG1_SEED_PIXEL, np.int32),
+         mask_bits=np.packbits(mask), bbox=np.array(bbox, np.int32), n_keep=np.int32(len(choose)), center=center,
+         choose_idx=choose_idx.astype(np.int32), pts=pts, rgb_choose=rgb_choose.astype(np.int64), model=model_points,
+         model_radius=np.float32(radius), tem_pts=tem_pts, tem_idx=tem_idx.to(torch.int16), feat_seed=np.int32(1), weights_seed=np.int32(1),
+         radius=rad_t, dense_pm=dense_pm, dense_po=dense_po, R=R, t=t, score=sc, R0=R0, t0=t0, fps_m=im.to(torch.int16),
+         fps_o=io_.to(torch.int16))
 
 
 # ----------------------------------------------------------------------------------------------------- ISM
@@ -674,7 +796,7 @@ def fx_rle():
 
 
 ALL = ["pointops", "pairwise", "geo", "transformer", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
-       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "ism", "rle"]
+       "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "config1", "ism", "rle"]
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

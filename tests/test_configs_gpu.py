@@ -1,0 +1,197 @@
+"""GPU parity on BASELINE.json's configurations, through the C ABI via sam6d_hip:
+
+* config 1 -- the demo Example (real depth map, camera and CAD model; tests/golden/config1.npz, written by oracle/gen_golden.py
+  fx_config1 from the reference's own modules): get_test_data geometry, template FPS, radius normalisation, then the whole matching
+  path, against the reference's outputs;
+* config 2 at full size -- B = 32 proposals in one pem_match call against the CPU oracle on 8 of them;
+* config 4 on one GPU -- 200 proposals dealt round-robin to 8 shards, every shard through pem_match, the gathered rows put back in
+  global order: bit-for-bit the unsharded result;
+* the fine stage's label / weight work (index work) against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import golden
+from tests.test_oracle_golden import config1_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _close(got, want, atol, what=""):
+    got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().float().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.isfinite(got).all(), what + ": non-finite values"
+    d = np.abs(got.astype(np.float64) - want.astype(np.float64)).max()
+    assert d <= atol, "%s: max abs diff %.3e > %.1e" % (what, d, atol)
+    return d
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from sam6d_hip import synth
+    return synth.make_pem_weights(1)
+
+
+@pytest.fixture(scope="module")
+def W(sd, dev):
+    from sam6d_hip import pem
+    return pem.PemWeights(sd, dev)
+
+
+# ------------------------------------------------------------------------------------------------------- config 1
+def test_config1_test_data_geometry_bit_exact(dev):
+    """Real depth map + camera: depth -> cloud, mask & depth > 0, crop box, radius filter, the caller's 2048 random picks and the
+    resized-crop indices (PEM/run_inference_custom_pytorch.py:292-355), bit-exact against the reference's own helpers."""
+    from sam6d_hip import pem
+    g = golden("config1")
+    depth = (g["depth_u16"].astype(np.float32) * np.float32(g["depth_scale"]) / np.float32(1000.0)).astype(np.float32)
+    mask = np.unpackbits(g["mask_bits"])[: 480 * 640].reshape(1, 480, 640)
+    geom = pem.proposal_geometry(torch.from_numpy(mask).to(dev), torch.from_numpy(depth).to(dev), g["K"], float(g["model_radius"]))
+    assert geom["bbox"][0].cpu().tolist() == [int(v) for v in g["bbox"]]
+    assert int(geom["n_keep"][0]) == int(g["n_keep"])
+    assert np.array_equal(geom["center"][0].cpu().numpy(), g["center"])
+    pts, rc = pem.proposal_choose(geom, torch.from_numpy(g["choose_idx"])[None].to(dev), 224)
+    assert np.array_equal(pts[0].cpu().numpy(), g["pts"]), "observed points"
+    assert np.array_equal(rc[0].cpu().numpy(), g["rgb_choose"]), "rgb_choose"
+
+
+def test_config1_template_fps_and_radius_bit_exact(dev):
+    """5000 CAD surface points -> 2048 by FPS (get_obj_feats' sample_pts_feats) and ViTEncoder.forward's radius normalisation
+    (PEM/model/feature_extraction.py:133-137) on the real CAD geometry."""
+    from sam6d_hip import ops, pem
+    g = golden("config1")
+    tem = torch.from_numpy(g["tem_pts"])[None].to(dev)
+    idx = ops.furthest_point_sampling(tem, 2048)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int16), g["tem_idx"])
+    po_raw = tem[0][idx[0].long()][None].contiguous()
+    pm, po, radius = pem.radius_normalize(torch.from_numpy(g["pts"])[None].to(dev), po_raw)
+    assert np.array_equal(radius.cpu().numpy(), g["radius"])
+    assert np.array_equal(pm.cpu().numpy(), g["dense_pm"]) and np.array_equal(po.cpu().numpy(), g["dense_po"])
+
+
+def test_config1_matching_path_vs_reference(dev, W):
+    """The demo proposal through the whole matching path: FPS indices bit-exact, poses and score within 1e-4 of the reference."""
+    from sam6d_hip import pem
+    g = golden("config1")
+    inp = config1_inputs(g)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    R, t, s, aux = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"],
+                                 return_aux=True)
+    assert np.array_equal(aux["fps_idx_m"].cpu().numpy().astype(np.int16), g["fps_m"])
+    assert np.array_equal(aux["fps_idx_o"].cpu().numpy().astype(np.int16), g["fps_o"])
+    _close(aux["init_R"], g["R0"], 1e-4, "coarse R"); _close(aux["init_t"], g["t0"], 1e-4, "coarse t")
+    _close(R, g["R"], 1e-4, "R"); _close(t, g["t"], 1e-4, "t"); _close(s, g["score"], 1e-4, "score")
+    # the default (fused, no aux) path must give the same poses
+    R2, t2, s2 = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+    _close(R2, g["R"], 1e-4, "R (fused)"); _close(t2, g["t"], 1e-4, "t (fused)"); _close(s2, g["score"], 1e-4, "score (fused)")
+
+
+# ------------------------------------------------------------------------------------------------------- config 2
+def test_config2_full_batch_vs_oracle(dev, W, sd):
+    """B = 32 (the benchmark's step) in ONE pem_match call; the CPU oracle runs proposals 0, 5, ... one at a time."""
+    from oracle import pem_oracle as O
+    from sam6d_hip import pem, synth
+    inp = synth.config2_inputs(B=32, seed=1)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    R, t, s = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+    torch.cuda.synchronize()
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(s).all()
+    _close(torch.linalg.det(R.cpu().double()).float(), torch.ones(32), 1e-5, "proper rotations")
+    picks = [0, 5, 9, 14, 18, 23, 27, 31]
+    torch.set_num_threads(min(16, torch.get_num_threads() or 8))
+    for b in picks:
+        sl = lambda k: inp[k][b:b + 1].contiguous()
+        with torch.no_grad():
+            oR, ot, os_ = O.pem_match(sl("dense_pm"), sl("dense_fm"), sl("dense_po"), sl("dense_fo"), sl("radius"), sl("model"), sd,
+                                      sl("rand"))
+        _close(R[b:b + 1], oR, 1e-4, "R[%d]" % b); _close(t[b:b + 1], ot, 1e-4, "t[%d]" % b); _close(s[b:b + 1], os_, 1e-4, "s[%d]" % b)
+
+
+# ------------------------------------------------------------------------------------------------------- config 4
+def test_config4_sharded_equals_unsharded(dev, W):
+    """200 proposals (8 objects x 25) dealt round-robin to 8 ranks (shard_indices), each shard through pem_match, rows gathered
+    rank-major and put back with unshard: identical, bit for bit, to the 200 proposals in one call -- every kernel treats a proposal
+    independently of its batch neighbours, so the sharded multi-GPU job returns exactly the single-GPU poses."""
+    from sam6d_hip import parallel, pem, synth
+    n_total, world = 200, 8
+    inp = synth.config2_inputs(B=n_total, seed=4)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    R, t, s = pem.pem_match(*[d[k] for k in keys], W, d["rand"])
+    whole = parallel.pack_poses(R, t, s)
+    blocks = []
+    for r in range(world):
+        ids, n_valid = parallel.shard_indices(n_total, r, world)
+        ids = ids.to(dev)
+        assert n_valid == 25 and len(ids) == 25
+        Rr, tr, sr = pem.pem_match(*[d[k][ids].contiguous() for k in keys], W, d["rand"][ids].contiguous())
+        blocks.append(parallel.pack_poses(Rr, tr, sr))
+    gathered = torch.cat(blocks, 0)  # what all_gather_into_tensor returns: rank-major
+    back = parallel.unshard(gathered, n_total, world)
+    torch.cuda.synchronize()
+    assert torch.isfinite(back).all()
+    nbad = int((back != whole).any(dim=1).sum())
+    assert nbad == 0, "%d of %d proposals differ between the sharded and the unsharded run (max |d| %.3e)" % (
+        nbad, n_total, float((back - whole).abs().max()))
+
+
+def test_config4_ragged_shards(dev, W):
+    """13 proposals over 4 ranks: the padded rows (last id repeated) are dropped by unshard."""
+    from sam6d_hip import parallel, pem, synth
+    n_total, world = 13, 4
+    inp = synth.config2_inputs(B=n_total, seed=6)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    whole = parallel.pack_poses(*pem.pem_match(*[d[k] for k in keys], W, d["rand"]))
+    blocks = []
+    for r in range(world):
+        ids, n_valid = parallel.shard_indices(n_total, r, world)
+        ids = ids.to(dev)
+        blocks.append(parallel.pack_poses(*pem.pem_match(*[d[k][ids].contiguous() for k in keys], W, d["rand"][ids].contiguous())))
+    back = parallel.unshard(torch.cat(blocks, 0), n_total, world)
+    assert torch.equal(back, whole)
+
+
+# ------------------------------------------------------------------------------------ fine-stage labels (index work)
+def _kat_atten(p1, p2, sharp=4.0, bg=-10.0):
+    d = torch.cdist(p1, p2)
+    att = torch.full((p1.shape[0], p1.shape[1] + 1, p2.shape[1] + 1), bg)
+    att[:, 1:, 1:] = (1 - sharp * d).clamp(min=-1) / 0.1
+    return att
+
+
+@pytest.mark.parametrize("which", ["kat", "flat"])
+def test_fine_stage_labels_and_weights_vs_oracle(dev, which):
+    """soft assignment of the 2049 x 2049 fine attention (PEM/utils/model_utils.py:308-318): the argmax labels of both sides are index
+    work (bit-exact against the oracle); assignment weights and weighted targets to 1e-5 (the label passes use the hardware exp / rcp
+    instructions)."""
+    from oracle import pem_oracle as O
+    from sam6d_hip import _lib, pem
+    g = golden("fine_rt")
+    p1, p2, Rg, tg = _t(g["p1"]), _t(g["p2"]), _t(g["R_gt"]), _t(g["t_gt"])
+    if which == "kat":
+        att = _kat_atten((p1 - tg.unsqueeze(1)) @ Rg, p2, float(g["sharp"]), float(g["bg"]))
+    else:
+        att = torch.randn(1, 2049, 2049, generator=torch.Generator().manual_seed(int(g["att2_seed"]))) * float(g["att2_scale"])
+    S, l1, l2 = O.soft_assignment(att)
+    A = S[:, 1:, 1:] * (l1 > 0).float().unsqueeze(2) * (l2 > 0).float().unsqueeze(1)
+    want_w = A.sum(2)
+    want_pred = (A / (A.sum(2, keepdim=True) + 1e-6)) @ p2
+    a = att.to(dev).contiguous()
+    st = pem.soft_assign(a)
+    n1 = int((st["l1"].cpu() != l1.to(torch.int32)).sum()); n2 = int((st["l2"].cpu() != l2.to(torch.int32)).sum())
+    assert n1 == 0 and n2 == 0, "labels differ from the oracle: %d of %d rows, %d of %d columns" % (n1, l1.numel(), n2, l2.numel())
+    B, R_, Cn = a.shape
+    pred = torch.empty(B, R_ - 1, 3, device=dev)
+    wgt = torch.empty(B, R_ - 1, device=dev)
+    _lib.call("sam6d_fine_assign", a.data_ptr(), B, R_, Cn, st["rmax"].data_ptr(), st["rsum"].data_ptr(), st["cmax"].data_ptr(),
+              st["csum"].data_ptr(), st["l1"].data_ptr(), st["l2"].data_ptr(), p2.to(dev).contiguous().data_ptr(), pred.data_ptr(),
+              wgt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _close(wgt, want_w, 1e-5, "assignment weights")
+    _close(pred, want_pred, 1e-5, "weighted targets")

@@ -211,6 +211,46 @@ def test_pem_end_to_end_seam(sd):
     np.testing.assert_allclose(s.numpy(), g["kat_score"], atol=1e-4, rtol=0)
 
 
+def config1_inputs(g):
+    """Seam inputs of SURVEY 8d config 1 from tests/golden/config1.npz (same generator walk as oracle/gen_golden.py:fx_config1):
+    geometry from the fixture, features N(0,1) / uniforms from seed `feat_seed`; dense_fo = the template features at the FPS picks."""
+    gen = torch.Generator().manual_seed(int(g["feat_seed"]))
+    tem_feat = torch.randn(1, 5000, 256, generator=gen)
+    dense_fm = torch.randn(1, 2048, 256, generator=gen)
+    rand = torch.rand(1, 18000, generator=gen)
+    dense_fo = tem_feat[:, torch.from_numpy(g["tem_idx"].astype(np.int64))[0]].contiguous()
+    return dict(dense_pm=torch.from_numpy(g["dense_pm"]), dense_fm=dense_fm, dense_po=torch.from_numpy(g["dense_po"]), dense_fo=dense_fo,
+                radius=torch.from_numpy(g["radius"]), model=torch.from_numpy(g["model"])[None].contiguous(), rand=rand)
+
+
+def test_config1_example_seam(sd):
+    """SURVEY 8d config 1 (demo Example: real depth map, camera, CAD model): the oracle against the reference's outputs, plus the
+    data-preparation steps that feed the seam (template FPS, radius normalisation, get_test_data geometry)."""
+    g = golden("config1")
+    inp = config1_inputs(g)
+    R, t, s, aux = O.pem_match(inp["dense_pm"], inp["dense_fm"], inp["dense_po"], inp["dense_fo"], inp["radius"], inp["model"], sd,
+                               inp["rand"], return_aux=True)
+    assert np.array_equal(aux["fps_idx_m"].numpy().astype(np.int16), g["fps_m"])
+    assert np.array_equal(aux["fps_idx_o"].numpy().astype(np.int16), g["fps_o"])
+    np.testing.assert_allclose(aux["init_R"].numpy(), g["R0"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(R.numpy(), g["R"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(t.numpy(), g["t"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(s.numpy(), g["score"], atol=1e-4, rtol=0)
+    # template FPS on the CAD surface sample, radius normalisation
+    tem = torch.from_numpy(g["tem_pts"])[None]
+    idx = P.furthest_point_sampling(tem, 2048)
+    assert np.array_equal(idx.numpy().astype(np.int16), g["tem_idx"])
+    pm, po, radius = O.radius_normalize(torch.from_numpy(g["pts"])[None], tem[:, idx[0].long()])
+    assert np.array_equal(pm.numpy(), g["dense_pm"]) and np.array_equal(po.numpy(), g["dense_po"]) and np.array_equal(radius.numpy(), g["radius"])
+    # get_test_data geometry on the real depth map
+    depth = (g["depth_u16"].astype(np.float32) * np.float32(g["depth_scale"]) / np.float32(1000.0)).astype(np.float32)
+    mask = np.unpackbits(g["mask_bits"])[: 480 * 640].reshape(480, 640)
+    o = O.proposal_geometry(mask, depth, g["K"], np.float32(g["model_radius"]))
+    assert o["bbox"] == [int(v) for v in g["bbox"]] and len(o["choose"]) == int(g["n_keep"]) and np.array_equal(o["center"], g["center"])
+    assert np.array_equal(o["cloud"][g["choose_idx"]], g["pts"])
+    assert np.array_equal(O.get_resize_rgb_choose(o["choose"][g["choose_idx"]], o["bbox"], 224), g["rgb_choose"])
+
+
 # ------------------------------------------------------------------------------------------------ ISM (a15-a18)
 def ism_inputs(seed=0):
     """Same generator walk as oracle/gen_golden.py:fx_ism."""
