@@ -57,6 +57,45 @@ def cpu_baseline(sd, nprop, threads):
     return nprop / dt, dt, (R, t, s), inp
 
 
+def launch_ranks(n, argv, script=None, extra_env=None, check_devices=True):
+    """Start `n` fresh child processes of `script` (default: this file), one rank per GPU, and wait for them.  Used when
+    `--gpus N` (N > 1) is given without a launcher (WORLD_SIZE unset).  The parent makes NO GPU call: it only counts devices
+    (torch.cuda.device_count() does not initialise HIP on this image) and hands every child RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT -- the same environment torch.distributed.run provides.  Children inherit stdout (rank 0 prints
+    the JSON line).  Returns the first non-zero exit code (the remaining ranks are then terminated by PID), else 0."""
+    import socket
+    import subprocess
+    if check_devices:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs, found %d -- refusing to run fewer ranks than asked\n" % (n, n, have))
+            return 2
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            try:
+                code = pr.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:  # a failed rank would leave the others waiting in the collective
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,17 +105,27 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one -- N fresh children, started before anything in this process touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d (or without a "
+                         "launcher: bench.py starts the ranks itself)\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)\n" % (rank, local, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == world
 
     import sam6d_hip
     sam6d_hip.require_lib()
@@ -189,10 +238,11 @@ def main():
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (fp16x3 split-precision MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": "PEM batch=%d proposals/GPU, 2048 scene + 2048 model pts, 1024 CAD pts, random-init weights "
                                    "(SURVEY 8d config 2)" % B, "proposals_per_gpu": B, "parallelism": "proposal-sharded x%d, "
                                    "RCCL all-gather of 13 floats/proposal" % world,
+                       "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                        "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA",
                        "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding"},
             "roofline": roofline,
