@@ -95,6 +95,30 @@ int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, fl
 int sam6d_gemm_ln256(const float* A, const float* W, const float* bias, const float* residual, const float* gamma,
                      const float* beta, float* Y, int M, int K, long lda, long ldw, long ldr, long ldy, float eps, void* stream);
 
+/* Fused transformer-block kernels (csrc/block.hip): a tile of 128 token rows (256 channels) stays on chip from the block's input to
+ * its second LayerNorm; split-precision (fp16 x3) MFMA arithmetic with power-of-two operand scaling (range-safe for any finite fp32
+ * input: no operand can overflow fp16).
+ * sam6d_token_block: the tail of every attention layer -- AttentionLayer / RPEAttentionLayer after the attention itself, then
+ *   AttentionOutput (PEM/model/transformer.py:152-160, 184-199, 436-444):
+ *     y = LayerNorm(hidden . Wlin^T + b + x);  out = LayerNorm(relu(y . Wexp^T + b) . Wsq^T + b + y)        all (M,256)
+ * sam6d_linattn_layer: the whole LinearTransformerLayer of the dense lift (PEM/model/transformer.py:532-622) on rows row0 .. I-1 of
+ *   each of the B clouds of D (B,I,256): proj_q, focused kernel function, z, (phi(q) kv) z per head, then the tail above with x = D.
+ *   kvimage / kvinv: sam6d_linattn_kv_pack of the (B,4,64,64) kv^T that sam6d_linattn_kv returns; ksum (B,256) its key sums.
+ * wimage: the layer's weights as the kernels' LDS panel image (sam6d_token_block_image_bytes(mode) bytes, mode 1 = with proj_q),
+ *   written by sam6d_pack_panels: rows x K fp32 -> 32-row panels of fp16 hi/lo halves, K in `ksteps` steps of 16 from column k0,
+ *   values multiplied by `scale` (a power of two).  Image order: linear (8 panels, K=256) | 4 x { expand rows 128c.. (4 panels,
+ *   K=256), squeeze columns 128c.. (8 panels, K=128) } | proj_q (8 panels, K=256; mode 1).
+ * consts: 2568 floats: b_q | 1/softplus(scale) | b_lin | gamma1 | beta1 | b_expand (512) | b_squeeze | gamma2 | beta2 |
+ *   {1/s_q, 1/s_lin, 1/s_exp, 1/(s_sq s_h), s_h, 0, 0, 0} with s_* the pack scales and s_h the scale of the FFN hidden row. */
+int sam6d_pack_panels(const float* W, long ldw, int rows, int k0, int ksteps, float scale, void* dst, void* stream);
+long sam6d_token_block_image_bytes(int mode);
+long sam6d_linattn_kv_image_bytes(void);
+int sam6d_linattn_kv_pack(const float* kvT, int B, void* image, float* inv, void* stream);
+int sam6d_token_block(const float* hidden, const float* x, const void* wimage, const float* consts, float* out, long M, float eps,
+                      void* stream);
+int sam6d_linattn_layer(const float* D, const void* wimage, const float* consts, const void* kvimage, const float* kvinv,
+                        const float* ksum, float* Dout, int B, int I, int row0, float eps, void* stream);
+
 /* replaces GeometricStructureEmbedding.forward (PEM/model/transformer.py:343-363; indices :306-341; sinusoid :259-285).
  * points (B,n,3) (bg point already prepended) -> out (B,n,n,256).  Workspaces: knn_ws (B*n*3 + 1) i32 (the last int is
  * the "index beyond the fast-sincos range" flag), idx_ws (B*n*n*4) f32. */

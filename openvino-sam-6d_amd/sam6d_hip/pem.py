@@ -39,6 +39,64 @@ class Linear:
         self.w, self.b = w.contiguous(), (b.contiguous() if b is not None else None)
 
 
+TB_P256, TB_P128, TB_P64 = 33 * 1024, 17 * 1024, 9 * 1024  # panel bytes of csrc/block.hip (32 rows x K = 256 / 128 / 64)
+TB_CHUNK = 4 * TB_P256 + 8 * TB_P128
+TB_Q_OFF = 8 * TB_P256 + 4 * TB_CHUNK
+
+
+def _pow2_scale(amax):
+    """Power of two s with amax * s in [2^13, 2^14) (the fp16 split then neither overflows nor reaches subnormals)."""
+    amax = float(amax)
+    if not (amax > 0.0 and math.isfinite(amax)):
+        return 1.0
+    return 2.0 ** (14 - math.frexp(amax)[1])
+
+
+def pack_token_block(L, q=None, scale=None):
+    """The LDS panel image + constant vector of csrc/block.hip for one layer tail L = {lin, n1, exp, sq, n2} (mode 0) or, with the
+    dense layer's proj_q `q` and focusing `scale`, for a whole LinearTransformerLayer (mode 1).  Pure data movement plus the
+    power-of-two operand scales (max / norms taken once, at weight-load time)."""
+    dev = L["lin"].w.device
+    mode = 1 if q is not None else 0
+    nbytes = int(_lib.load().sam6d_token_block_image_bytes(mode))
+    assert nbytes == TB_Q_OFF + (8 * TB_P256 if mode else 0)
+    img = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+
+    def pk(Wt, row0, rows, k0, ksteps, sc, off):
+        ld = Wt.shape[1]
+        _lib.call("sam6d_pack_panels", _p(Wt, row0 * ld), ld, rows, k0, ksteps, float(sc), img.data_ptr() + off, _s())
+
+    s_lin = _pow2_scale(L["lin"].w.abs().max())
+    s_exp = _pow2_scale(L["exp"].w.abs().max())
+    s_sq = _pow2_scale(L["sq"].w.abs().max())
+    pk(L["lin"].w, 0, C, 0, 8, s_lin, 0)
+    for c in range(4):
+        base = 8 * TB_P256 + c * TB_CHUNK
+        pk(L["exp"].w, 128 * c, 128, 0, 8, s_exp, base)
+        pk(L["sq"].w, 0, C, 128 * c, 4, s_sq, base + 4 * TB_P256)
+    s_q = 1.0
+    if mode:
+        s_q = _pow2_scale(q.w.abs().max())
+        pk(q.w, 0, C, 0, 8, s_q, TB_Q_OFF)
+    # bound of the FFN hidden row (Cauchy-Schwarz; |LayerNorm output|_2 <= 16 max|gamma| + |beta|_2): its scale must be known
+    # before the chunks accumulate
+    g1, b1 = L["n1"]
+    ymax = 16.0 * float(g1.abs().max()) + float(b1.norm())
+    hmax = float(L["exp"].w.norm(dim=1).max()) * ymax + float(L["exp"].b.abs().max())
+    s_h = _pow2_scale(hmax)
+    cst = torch.zeros(2568, dtype=torch.float32, device=dev)
+    if mode:
+        cst[0:256] = q.b
+        cst[256:512] = 1.0 / torch.nn.functional.softplus(scale.reshape(-1))
+    cst[512:768] = L["lin"].b
+    cst[768:1024], cst[1024:1280] = g1, b1
+    cst[1280:1792] = L["exp"].b
+    cst[1792:2048] = L["sq"].b
+    cst[2048:2304], cst[2304:2560] = L["n2"]
+    cst[2560:2565] = torch.tensor([1.0 / s_q, 1.0 / s_lin, 1.0 / s_exp, 1.0 / (s_sq * s_h), s_h], device=dev)
+    return dict(img=img, cst=cst, mode=mode)
+
+
 class PemWeights:
     """Device-resident weights in the layouts the kernels want, built from a reference-keyed state_dict
     (SURVEY 8b B2).  Packing is pure data movement: concatenating q/k/v projection weights, transposing proj_p, folding
@@ -66,6 +124,7 @@ class PemWeights:
                 kv=Linear(torch.cat([g(a + ".proj_k.weight"), g(a + ".proj_v.weight")], 0),
                           torch.cat([g(a + ".proj_k.bias"), g(a + ".proj_v.bias")], 0)),
                 **self._post(g, d))
+            blk["dense"]["tbd"] = pack_token_block(blk["dense"], blk["dense"]["q"], blk["dense"]["scale"])
             self.fine["blocks"].append(blk)
         pe = "fine_point_matching.PE"
         self.pe = dict(mlp=[], mlp3=Linear(g(pe + ".mlp3.conv.weight").reshape(C, C), g(pe + ".mlp3.conv.bias")))
@@ -88,11 +147,13 @@ class PemWeights:
 
     @staticmethod
     def _post(g, p):
-        return dict(lin=Linear(g(p + ".attention.linear.weight"), g(p + ".attention.linear.bias")),
-                    n1=(g(p + ".attention.norm.weight"), g(p + ".attention.norm.bias")),
-                    exp=Linear(g(p + ".output.expand.weight"), g(p + ".output.expand.bias")),
-                    sq=Linear(g(p + ".output.squeeze.weight"), g(p + ".output.squeeze.bias")),
-                    n2=(g(p + ".output.norm.weight"), g(p + ".output.norm.bias")))
+        L = dict(lin=Linear(g(p + ".attention.linear.weight"), g(p + ".attention.linear.bias")),
+                 n1=(g(p + ".attention.norm.weight"), g(p + ".attention.norm.bias")),
+                 exp=Linear(g(p + ".output.expand.weight"), g(p + ".output.expand.bias")),
+                 sq=Linear(g(p + ".output.squeeze.weight"), g(p + ".output.squeeze.bias")),
+                 n2=(g(p + ".output.norm.weight"), g(p + ".output.norm.bias")))
+        L["tb"] = pack_token_block(L)  # the fused layer tail's weight image (csrc/block.hip)
+        return L
 
     def _geo_transformer(self, g, p):
         s, c = p + ".layers.0", p + ".layers.1"
@@ -137,6 +198,7 @@ def pack_sparse_to_dense(sd, device, p):
     blk["dense"] = dict(scale=g(a + ".scale").reshape(-1), q=Linear(g(a + ".proj_q.weight"), g(a + ".proj_q.bias")),
                         kv=Linear(torch.cat([g(a + ".proj_k.weight"), g(a + ".proj_v.weight")], 0),
                                   torch.cat([g(a + ".proj_k.bias"), g(a + ".proj_v.bias")], 0)), **PemWeights._post(g, d))
+    blk["dense"]["tbd"] = pack_token_block(blk["dense"], blk["dense"]["q"], blk["dense"]["scale"])
     return blk
 
 
@@ -196,6 +258,14 @@ def layernorm(x2d, gb, out=None):
 def _post_attention(hidden, x2d, L):
     """linear -> +residual -> LayerNorm -> AttentionOutput (expand, ReLU, squeeze, +residual, LayerNorm)
     (PEM/model/transformer.py:152-199)."""
+    if _fused_block() and "tb" in L:
+        # linear + residual + LayerNorm + FFN + residual + LayerNorm in ONE launch: the 128-token tile never leaves the chip
+        M = hidden.shape[0]
+        out = _empty((M, C), hidden)
+        tb = L["tb"]
+        with _Timed("token_block"):
+            _lib.call("sam6d_token_block", _p(hidden), _p(x2d), tb["img"].data_ptr(), _p(tb["cst"]), _p(out), M, 1e-5, _s())
+        return out
     # SAM6D_FUSED_LN=1: projection + residual + LayerNorm in one launch (sam6d_gemm_ln256).  Off by default: measured 1 % slower
     # than the two launches (64-row tiles at 184 registers and 4-byte stores cost what the saved LayerNorm pass gives back).
     if _lib.load().sam6d_get_matmul_mode() == 1 and os.environ.get("SAM6D_FUSED_LN", "0") == "1":
@@ -205,6 +275,12 @@ def _post_attention(hidden, x2d, L):
     y = layernorm(linear(hidden, L["lin"], residual=x2d), L["n1"])
     h = linear(y, L["exp"], act=1)
     return layernorm(linear(h, L["sq"], residual=y), L["n2"])
+
+
+def _fused_block():
+    """The fused transformer-block kernels (csrc/block.hip) serve the split-precision mode; SAM6D_FUSED_BLOCK=0 keeps the
+    launch-per-op path (also what matmul mode 0, the exact fp32 MFMA reference arithmetic, uses)."""
+    return _lib.load().sam6d_get_matmul_mode() == 1 and os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1"
 
 
 def gemm_ln(x, lin, residual, norm, eps=1e-5):
@@ -447,15 +523,26 @@ def linear_transformer_layer(D, S, L):
     J = S.shape[1] - 1
     rows = Bp * I
     D2 = D.reshape(rows, C)
-    q = linear(D2, L["q"])
-    kv = _empty((Bp, J, 2 * C), D)
-    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C)
     if not (I * J * 128 > 64 * 64 * (I + J)):
         raise RuntimeError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
+    kv = _empty((Bp, J, 2 * C), D)
+    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C)
     _lib.call("sam6d_linattn_focus_k", _p(kv), _p(L["scale"]), Bp * J, 2 * C, _s())
     kvT = _empty((Bp, H, 64, 64), D)
     ksum = _empty((Bp, H, 64), D)
     _lib.call("sam6d_linattn_kv", _p(kv), _p(kv, C), Bp, J, 2 * C, 2 * C, J * 2 * C, J * 2 * C, _p(kvT), _p(ksum), _s())
+    if _fused_block() and "tbd" in L:
+        # the whole layer on the dense tokens (rows 1 .. I-1 of every cloud) in one launch; row 0 (the bg slot) is written by the caller
+        tb = L["tbd"]
+        kvimg = torch.empty(Bp * TB_P64 * 8, dtype=torch.uint8, device=D.device)
+        kvinv = _empty((Bp,), D)
+        _lib.call("sam6d_linattn_kv_pack", _p(kvT), Bp, kvimg.data_ptr(), _p(kvinv), _s())
+        Dn = _empty((Bp, I, C), D)
+        with _Timed("linattn_layer"):
+            _lib.call("sam6d_linattn_layer", _p(D), tb["img"].data_ptr(), _p(tb["cst"]), kvimg.data_ptr(), _p(kvinv), _p(ksum), _p(Dn),
+                      Bp, I, 1, 1e-5, _s())
+        return Dn
+    q = linear(D2, L["q"])
     _lib.call("sam6d_linattn_focus_q", _p(q), _p(L["scale"]), _p(ksum), Bp, I, C, _s())
     hid = _empty((rows, C), D)
     for h in range(H):  # x_h = (phi(q)_h z) @ kv_h : batched over B'

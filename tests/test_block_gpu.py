@@ -1,0 +1,121 @@
+"""GPU parity of the fused transformer-block kernels (csrc/block.hip) through the C ABI: the layer tail (linear + residual + LayerNorm +
+FFN + residual + LayerNorm; PEM/model/transformer.py:152-160, 184-199) and the whole dense LinearTransformerLayer (:532-622), against a
+float64 recompute and the CPU oracle; operand magnitudes far outside fp16's range check the power-of-two scaling."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(gen, wscale=1.0):
+    from sam6d_hip import pem
+    mk = lambda o, i: pem.Linear((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i) * wscale, (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    return dict(lin=mk(256, 256), n1=(1 + 0.1 * torch.randn(256, generator=gen), 0.1 * torch.randn(256, generator=gen)), exp=mk(512, 256),
+                sq=mk(256, 512), n2=(1 + 0.1 * torch.randn(256, generator=gen), 0.1 * torch.randn(256, generator=gen)))
+
+
+def _to(L, dev):
+    from sam6d_hip import pem
+    out = {}
+    for k, v in L.items():
+        if isinstance(v, pem.Linear):
+            out[k] = pem.Linear(v.w.to(dev), v.b.to(dev))
+        elif isinstance(v, tuple):
+            out[k] = tuple(x.to(dev).contiguous() for x in v)
+        else:
+            out[k] = v.to(dev)
+    return out
+
+
+def _tail64(hidden, x, L):
+    d = lambda t: t.double()
+    ln = lambda v, gb: torch.nn.functional.layer_norm(v, (256,), d(gb[0]), d(gb[1]), 1e-5)
+    y = ln(d(hidden) @ d(L["lin"].w).t() + d(L["lin"].b) + d(x), L["n1"])
+    h = torch.relu(y @ d(L["exp"].w).t() + d(L["exp"].b))
+    return ln(h @ d(L["sq"].w).t() + d(L["sq"].b) + y, L["n2"])
+
+
+@pytest.mark.parametrize("M,hs,ws", [(1, 1.0, 1.0), (127, 1.0, 1.0), (128, 1.0, 1.0), (1000, 1.0, 1.0), (12608, 1.0, 1.0),
+                                     (300, 1.0e5, 1.0), (300, 1.0e-6, 1.0), (300, 3.0, 300.0), (300, 1.0, 1.0e-4)])
+def test_token_block_vs_fp64(dev, M, hs, ws):
+    """hs scales the attention output (1e5: beyond fp16's 65504; 1e-6: every lo half would be a subnormal without the row scale),
+    ws the linear weight."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(M + int(math.log10(hs) * 7) + int(math.log10(ws) * 3))
+    L = _layer(gen)
+    L["lin"] = pem.Linear(L["lin"].w * ws, L["lin"].b)
+    hidden = torch.randn(M, 256, generator=gen) * hs
+    x = torch.randn(M, 256, generator=gen) * (hs * ws if hs * ws > 1 else 1.0)
+    want = _tail64(hidden, x, L)
+    Ld = _to(L, dev)
+    tb = pem.pack_token_block(Ld)
+    out = torch.full((M, 256), float("nan"), device=dev)
+    hd, xd = hidden.to(dev), x.to(dev)  # (named: a temporary would be freed, and its memory reused, before the launch)
+    _lib.call("sam6d_token_block", hd.data_ptr(), xd.data_ptr(), tb["img"].data_ptr(), tb["cst"].data_ptr(), out.data_ptr(), M, 1e-5,
+              torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < 2e-5, "token block vs fp64: %.3e" % err
+
+
+def test_token_block_matches_unfused_path(dev, monkeypatch):
+    """same layer through the launch-per-op path (GEMM, LayerNorm kernels) and the fused kernel"""
+    from sam6d_hip import pem
+    gen = torch.Generator().manual_seed(5)
+    Ld = _to(_layer(gen), dev)
+    Ld["tb"] = pem.pack_token_block(Ld)
+    hidden = torch.randn(777, 256, generator=gen).to(dev)
+    x = torch.randn(777, 256, generator=gen).to(dev)
+    a = pem._post_attention(hidden, x, Ld)
+    monkeypatch.setenv("SAM6D_FUSED_BLOCK", "0")
+    b = pem._post_attention(hidden, x, Ld)
+    assert float((a - b).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("Bp,I,qs", [(2, 2049, 1.0), (3, 300, 1.0), (1, 130, 1.0), (2, 257, 1.0e4), (2, 257, 1.0e-5)])
+def test_linattn_layer_vs_oracle_math(dev, Bp, I, qs):
+    """Whole dense layer on rows 1 .. I-1 against a float64 recompute of LinearAttention + tail (PEM/model/transformer.py:532-622);
+    qs scales the dense tokens (focused attention is scale-free in q up to the 1e-6 offsets, the residual / LayerNorm are not)."""
+    from sam6d_hip import pem
+    gen = torch.Generator().manual_seed(Bp * 1000 + I)
+    L = _layer(gen)
+    mk = lambda o, i: pem.Linear((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i), (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    L["q"], L["kv"] = mk(256, 256), mk(512, 256)
+    L["scale"] = 0.3 * torch.randn(256, generator=gen)
+    J = 196
+    D = torch.randn(Bp, I, 256, generator=gen) * qs
+    S = torch.randn(Bp, J + 1, 256, generator=gen)
+    # float64 reference
+    d = lambda t: t.double()
+    Dt = d(D[:, 1:])
+    mem = d(S[:, 1:])
+    q = Dt @ d(L["q"].w).t() + d(L["q"].b)
+    k = mem @ d(L["kv"].w[:256]).t() + d(L["kv"].b[:256])
+    v = mem @ d(L["kv"].w[256:]).t() + d(L["kv"].b[256:])
+    sp = torch.nn.functional.softplus(d(L["scale"]))
+
+    def phi(z):
+        z = (torch.relu(z) + 1e-6) / sp
+        n = z.norm(dim=-1, keepdim=True)
+        z3 = z ** 3
+        return z3 / z3.norm(dim=-1, keepdim=True) * n
+    q, k = phi(q), phi(k)
+    hid = torch.zeros_like(q)
+    for h in range(4):
+        sl = slice(64 * h, 64 * h + 64)
+        z = 1.0 / (torch.einsum("bic,bc->bi", q[..., sl], k[..., sl].sum(1)) + 1e-6)
+        kvm = torch.einsum("bjc,bjd->bcd", k[..., sl], v[..., sl])
+        hid[..., sl] = torch.einsum("bic,bcd,bi->bid", q[..., sl], kvm, z)
+    want = _tail64(hid, Dt, L)
+    Ld = _to(L, dev)
+    Ld["scale"] = L["scale"].to(dev)
+    Ld["tb"] = pem.pack_token_block(Ld)
+    Ld["tbd"] = pem.pack_token_block(Ld, Ld["q"], Ld["scale"])
+    got = pem.linear_transformer_layer(D.to(dev).contiguous(), S.to(dev).contiguous(), Ld)[:, 1:].cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < 5e-5, "dense linear-attention layer vs fp64: %.3e" % err
