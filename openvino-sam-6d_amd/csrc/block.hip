@@ -29,17 +29,22 @@
 // accumulator); the scales are undone exactly in the epilogues.  No operand can overflow fp16, no lo half falls into subnormals.
 #include "common.h"
 #include "../../include/sam6d_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#define TB_TOK 128                              // tokens per workgroup (8 waves x 16)
-#define TB_ROWB(KS) ((KS) * 128 + 32)           // bytes of one weight row in a panel: KS*32 hi halves | KS*32 lo halves | 32 B pad
-#define TB_PIECES(KS) ((32 * TB_ROWB(KS) + 1023) / 1024)  // 1 KiB DMA pieces per 32-row panel: 33 (K=256), 17 (K=128), 9 (K=64)
-#define TB_PANEL_BYTES (TB_PIECES(8) * 1024)    // 33 792
-#define TB_P256 (TB_PIECES(8) * 1024)
-#define TB_P128 (TB_PIECES(4) * 1024)
-#define TB_P64 (TB_PIECES(2) * 1024)
+// tokens per workgroup = 16 x waves: 64 (4 waves, 2-slot panel ring, two independent workgroups per CU) or 128 (8 waves, 4-slot ring)
+// A panel = 32 weight rows x K (KS k-steps of 32): per row KS*32 hi halves | KS*32 lo halves, NO padding -- instead the 16-byte chunk
+// c of row r is stored at chunk c ^ (r & 15), which makes the ds_read_b128 fragment reads (16 rows x 2 adjacent chunks per lane
+// group) conflict-free.  The global image is stored swizzled, so a linear LDS-DMA copy reproduces it.
+#define TB_ROWB(KS) ((KS) * 128)                // bytes of one weight row in a panel
+#define TB_PBYTES(KS) (32 * TB_ROWB(KS))        // 32 768 (K=256), 16 384 (K=128), 8 192 (K=64): 32 / 16 / 8 DMA pieces of 1 KiB
+#define TB_PANEL_BYTES TB_PBYTES(8)
+#define TB_P256 TB_PBYTES(8)
+#define TB_P128 TB_PBYTES(4)
+#define TB_P64 TB_PBYTES(2)
 #define TB_CHUNK_BYTES (4 * TB_P256 + 8 * TB_P128)  // one 128-wide FFN chunk: 4 expand panels + 8 squeeze panels
 #define TB_Q_OFF (8 * TB_P256 + 4 * TB_CHUNK_BYTES) // proj_q panels follow the common part of the image
 #define TB_IMAGE_BYTES(MODE) (TB_Q_OFF + ((MODE) ? 8 * TB_P256 : 0))
@@ -68,18 +73,19 @@ __host__ __device__ __forceinline__ int tb_slot_channel(int p) {
 __global__ __launch_bounds__(256) void tb_pack_kernel(const float* __restrict__ W, long ldw, int k0, int KS, float scale,
                                                       unsigned char* __restrict__ dst) {
   const int panel = blockIdx.x;
-  const int rowb = TB_ROWB(KS), pbytes = TB_PIECES(KS) * 1024;
-  unsigned char* out = dst + (size_t)panel * pbytes;
-  for (int i = threadIdx.x; i < pbytes / 2; i += 256) reinterpret_cast<_Float16*>(out)[i] = (_Float16)0.f;
-  __syncthreads();
+  const int rowb = TB_ROWB(KS);
+  unsigned char* out = dst + (size_t)panel * TB_PBYTES(KS);
   for (int i = threadIdx.x; i < 32 * KS * 32; i += 256) {
     const int m = i / (KS * 32), p = i % (KS * 32);
     const int col = k0 + 32 * (p >> 5) + tb_slot_channel(p & 31);
     const float v = W[(size_t)(panel * 32 + m) * ldw + col] * scale;
     const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    // logical half index -> 16-byte chunk (8 halves) -> swizzled chunk
+    const int ch = p >> 3, cl = (KS * 32 + p) >> 3;
     _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)m * rowb);
-    row[p] = hi;
-    row[KS * 32 + p] = (_Float16)(v - (float)hi);
+    row[((ch ^ (m & 15)) << 3) + (p & 7)] = hi;
+    row[((cl ^ (m & 15)) << 3) + (p & 7)] = lo;
   }
 }
 
@@ -116,16 +122,15 @@ __global__ __launch_bounds__(256) void tb_kv_pack_kernel(const float* __restrict
   const float scale = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
   if (t == 0) inv[b] = 1.0f / scale;
   unsigned char* out = dst + (size_t)b * (8 * TB_P64);
-  for (int i = t; i < 8 * TB_P64 / 2; i += 256) reinterpret_cast<_Float16*>(out)[i] = (_Float16)0.f;
-  __syncthreads();
   for (int i = t; i < 16384; i += 256) {
     const int hd = i >> 12, d = (i >> 6) & 63, p = i & 63;  // p: slot inside the 64-wide K
     const int c = 32 * (p >> 5) + tb_slot_channel(p & 31);
     const float v = src[(hd * 64 + d) * 64 + c] * scale;
     const _Float16 hi = (_Float16)v;
-    _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)(2 * hd + (d >> 5)) * TB_P64 + (size_t)(d & 31) * TB_ROWB(2));
-    row[p] = hi;
-    row[64 + p] = (_Float16)(v - (float)hi);
+    const int m = d & 31;
+    _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)(2 * hd + (d >> 5)) * TB_P64 + (size_t)m * TB_ROWB(2));
+    row[(((p >> 3) ^ (m & 15)) << 3) + (p & 7)] = hi;
+    row[((((64 + p) >> 3) ^ (m & 15)) << 3) + (p & 7)] = (_Float16)(v - (float)hi);
   }
 }
 
@@ -140,25 +145,71 @@ extern "C" long sam6d_token_block_image_bytes(int mode) { return mode ? TB_IMAGE
 extern "C" long sam6d_linattn_kv_image_bytes(void) { return 8 * TB_P64; }
 
 // ------------------------------------------------------------------------------------------------------- the kernel
-// one 32-row panel = two 16-row out tiles; KS k-steps of 32
+// one 32-row panel = two 16-row out tiles; KS k-steps of 32.  The weight fragments of step s+1 are requested before the six MFMAs
+// of step s are issued (the eight waves run in lock-step between the panel barriers, so nothing else hides the LDS latency).  The
+// reads and their counted waits are inline assembly: left to the compiler, the machine scheduler sinks every read to just before its
+// use and waits with lgkmcnt(0) (measured: 2.7x the MFMA time per panel).
+typedef unsigned tb_u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ tb_u32x4 tb_lds128(unsigned addr) {
+  tb_u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// wait until at most N LDS operations are outstanding; the fragments are in/out operands so that their uses stay behind the wait
+template <int N>
+__device__ __forceinline__ void tb_wait(tb_u32x4& a, tb_u32x4& b, tb_u32x4& c, tb_u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+// chunk (16 B) index of (plane P, step S, lane group g) in a row: P * KS * 4 + 4 S + g; its low four bits are XORed with the row:
+// the lane-dependent part ((4 q + g) ^ row) << 4 for q = 0..3 sits in four address registers, the rest is an immediate offset
+template <int KS, int P, int S>
+struct TbChunk {
+  static constexpr int c = P * KS * 4 + 4 * S;     // + g (g < 4 never carries out of the low two bits)
+  static constexpr int q = (c & 15) >> 2;
+  static constexpr int off = (c & ~15) * 16;
+};
+template <int KS, int S>
+__device__ __forceinline__ void tb_load_step(const unsigned (&a)[4], tb_u32x4* f) {
+  constexpr int R1 = 16 * TB_ROWB(KS);
+  typedef TbChunk<KS, 0, S> H;
+  typedef TbChunk<KS, 1, S> L;
+  f[0] = tb_lds128<H::off>(a[H::q]);
+  f[1] = tb_lds128<L::off>(a[L::q]);
+  f[2] = tb_lds128<R1 + H::off>(a[H::q]);
+  f[3] = tb_lds128<R1 + L::off>(a[L::q]);
+}
+// Fragment ring of TB_FD + 1 steps: the reads of step S + TB_FD are issued before the six MFMAs of step S (one step of MFMAs, 96
+// cycles, does not cover the LDS latency when all eight waves of the CU stream b128 reads).
+#define TB_FD 1
+template <int KS, int S>
+__device__ __forceinline__ void tb_mma_step(f32x4& acc0, f32x4& acc1, const unsigned (&a)[4], const half8* __restrict__ xh,
+                                            const half8* __restrict__ xl, tb_u32x4 (&f)[TB_FD + 1][4]) {
+  constexpr int cur = S % (TB_FD + 1);
+  if constexpr (S + TB_FD < KS) tb_load_step<KS, S + TB_FD>(a, f[(S + TB_FD) % (TB_FD + 1)]);
+  constexpr int newer = (KS - 1 - S) < TB_FD ? (KS - 1 - S) : TB_FD;  // steps requested after this one
+  tb_wait<4 * newer>(f[cur][0], f[cur][1], f[cur][2], f[cur][3]);
+  const half8 h0 = __builtin_bit_cast(half8, f[cur][0]), l0 = __builtin_bit_cast(half8, f[cur][1]);
+  const half8 h1 = __builtin_bit_cast(half8, f[cur][2]), l1 = __builtin_bit_cast(half8, f[cur][3]);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, xh[S], acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, xh[S], acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xl[S], acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xl[S], acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xh[S], acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xh[S], acc1, 0, 0, 0);
+  if constexpr (S + 1 < KS) tb_mma_step<KS, S + 1>(acc0, acc1, a, xh, xl, f);
+}
+// `panel`: LDS byte address of the panel; rows fr (first out tile) and fr + 16 (second)
 template <int KS>
-__device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, const unsigned char* __restrict__ panel, const half8* __restrict__ xh,
+__device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, unsigned panel, const half8* __restrict__ xh,
                                        const half8* __restrict__ xl, int fr, int fg) {
-  const unsigned char* row0 = panel + fr * TB_ROWB(KS) + fg * 16;
-  const unsigned char* row1 = row0 + 16 * TB_ROWB(KS);
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const half8 ah0 = *reinterpret_cast<const half8*>(row0 + s * 64);
-    const half8 al0 = *reinterpret_cast<const half8*>(row0 + KS * 64 + s * 64);
-    const half8 ah1 = *reinterpret_cast<const half8*>(row1 + s * 64);
-    const half8 al1 = *reinterpret_cast<const half8*>(row1 + KS * 64 + s * 64);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, xh[s], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, xh[s], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xl[s], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xl[s], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, xh[s], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, xh[s], acc1, 0, 0, 0);
-  }
+  const unsigned rowbase = panel + fr * TB_ROWB(KS);
+  const unsigned a[4] = {rowbase + (((0 + fg) ^ fr) << 4), rowbase + (((4 + fg) ^ fr) << 4), rowbase + (((8 + fg) ^ fr) << 4),
+                         rowbase + (((12 + fg) ^ fr) << 4)};
+  tb_u32x4 f[TB_FD + 1][4];
+  tb_load_step<KS, 0>(a, f[0]);
+  if constexpr (TB_FD >= 2 && KS >= 2) tb_load_step<KS, 1>(a, f[1]);
+  tb_mma_step<KS, 0>(acc0, acc1, a, xh, xl, f);
 }
 
 // a token's channels live in the four lanes 16 apart (g = lane >> 4): reductions over the token
@@ -173,7 +224,6 @@ __device__ __forceinline__ float tok_sum(float s) {
 
 // makes a register value opaque to the optimiser (no instruction): without it the compiler keeps the fp32 images of y's hi / lo
 // halves, computed while splitting, alive across the whole FFN for the second residual (128 VGPRs -> scratch spills)
-typedef unsigned tb_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tb_opaque(half8& x) {
   tb_u32x4 t = __builtin_bit_cast(tb_u32x4, x);
   asm volatile("" : "+v"(t));
@@ -241,14 +291,54 @@ struct TbArgs {
   float eps;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1
+template <int B, int E, class F>
+__device__ __forceinline__ void tb_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    tb_static_for<B + 1, E>(f);
+  }
+}
+
+// The panel sequence of a launch (MODE 1: proj_q x8, kv x8, then the common part; common: linear x8, 4 x {expand x4, squeeze x8}) and
+// the number of 1 KiB DMA pieces EACH WAVE copies for panel i (8 waves): 4 (K = 256), 2 (K = 128), 1 (K = 64), 0 past the end.
+template <int MODE, int WAVES>
+struct TbSched {
+  static constexpr int NPAN = (MODE ? 16 : 0) + 8 + 4 * 12;
+  static constexpr int per_wave(int i) {
+    if (i < 0 || i >= NPAN) return 0;
+    if (MODE) {
+      if (i < 8) return (32 + WAVES - 1) / WAVES;
+      if (i < 16) return (8 + WAVES - 1) / WAVES;
+      i -= 16;
+    }
+    if (i < 8) return (32 + WAVES - 1) / WAVES;
+    return ((((i - 8) % 12) < 4 ? 32 : 16) + WAVES - 1) / WAVES;
+  }
+  static constexpr int pieces(int i) {  // 1 KiB pieces of panel i
+    if (MODE && i >= 8 && i < 16) return 8;
+    const int k = MODE ? i - 16 : i;
+    return (k >= 8 && ((k - 8) % 12) >= 4) ? 16 : 32;
+  }
+  // pieces of the panels I+1 .. I+NBUF-2 (in flight while panel I is awaited)
+  template <int NBUF>
+  static constexpr int in_flight(int i) {
+    int n = 0;
+    for (int k = 1; k <= NBUF - 2; ++k) n += per_wave(i + k);
+    return n;
+  }
+};
+
+template <int MODE, int WAVES, int NBUF>
+__global__ __launch_bounds__(WAVES * 64) void token_block_kernel(TbArgs a) {
+  constexpr int TB_TOK = 16 * WAVES, TB_NBUF = NBUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* pan = lds;                                                   // 2 x TB_PANEL_BYTES
-  float* cst = reinterpret_cast<float*>(lds + 2 * TB_PANEL_BYTES);            // TC_N floats
+  unsigned char* pan = lds;                                                   // TB_NBUF x TB_PANEL_BYTES ring
+  float* cst = reinterpret_cast<float*>(lds + TB_NBUF * TB_PANEL_BYTES);      // TC_N floats
   float* ksm = cst + TC_N;                                                    // 256 floats (mode 1)
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fg = lane >> 4;
-  constexpr int NPAN = (MODE ? 16 : 0) + 8 + 4 * 12;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  typedef TbSched<MODE, WAVES> SCH;
+  const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pan;
 
   // ---- which rows
   long row;       // global row of this lane's token
@@ -266,45 +356,45 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
   }
 
   const unsigned char* kvp = MODE ? a.kvimg + (size_t)b * (8 * TB_P64) : nullptr;
-  auto dma = [&](int i) {
-    const unsigned char* src = a.wimg;
-    int pieces = TB_PIECES(8);
-    int k = i;
-    bool done = false;
-    if (MODE) {
-      if (k < 8) { src = a.wimg + TB_Q_OFF + (size_t)k * TB_P256; done = true; }
-      else if (k < 16) { src = kvp + (size_t)(k - 8) * TB_P64; pieces = TB_PIECES(2); done = true; }
-      k -= 16;
-    }
-    if (!done) {
-      if (k < 8) src = a.wimg + (size_t)k * TB_P256;
+  // LDS-DMA of panel I into ring slot I % TB_NBUF: SCH::per_wave(I) pieces of 1 KiB per wave (the global image IS the LDS image)
+  auto dma = [&](auto IC) {
+    constexpr int I = decltype(IC)::value;
+    constexpr int NP = SCH::per_wave(I);
+    if constexpr (NP > 0) {
+      constexpr int K = MODE ? I - 16 : I;   // index in the common part (negative: proj_q / kv panels)
+      const unsigned char* src;
+      if constexpr (MODE && I < 8) src = a.wimg + TB_Q_OFF + (size_t)I * TB_P256;
+      else if constexpr (MODE && I < 16) src = kvp + (size_t)(I - 8) * TB_P64;
+      else if constexpr (K < 8) src = a.wimg + (size_t)K * TB_P256;
       else {
-        k -= 8;
-        const int c = k / 12, u = k % 12;
-        const unsigned char* base = a.wimg + 8 * TB_P256 + (size_t)c * TB_CHUNK_BYTES;
-        if (u < 4) src = base + (size_t)u * TB_P256;
-        else { src = base + 4 * TB_P256 + (size_t)(u - 4) * TB_P128; pieces = TB_PIECES(4); }
+        constexpr int c = (K - 8) / 12, u = (K - 8) % 12;
+        constexpr size_t base = 8 * (size_t)TB_P256 + c * (size_t)TB_CHUNK_BYTES;
+        src = a.wimg + (u < 4 ? base + u * (size_t)TB_P256 : base + 4 * (size_t)TB_P256 + (u - 4) * (size_t)TB_P128);
+      }
+      unsigned char* dst = pan + (I % TB_NBUF) * TB_PANEL_BYTES;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int pc = wave + WAVES * k;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                         (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
       }
     }
-    unsigned char* dst = pan + (i & 1) * TB_PANEL_BYTES;
-    for (int pc = wave; pc < pieces; pc += 8)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
-                                       (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
   };
-  int pi = 0;
-  // the barrier both publishes panel pi (every wave's DMA pieces have landed: vmcnt) and retires panel pi-1, whose buffer the
-  // next DMA overwrites
-  auto next_panel = [&]() -> const unsigned char* {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Start of panel I: this wave's pieces of panel I have landed once at most the pieces of the panels issued after it (I+1 ..
+  // I+NBUF-2; the vector-memory counter retires in order) are outstanding; the barrier then publishes the panel to the other waves
+  // and at the same time retires panel I-1 in every wave, whose ring slot the DMA of panel I+NBUF-1 overwrites.
+  auto next_panel = [&](auto IC) -> unsigned {
+    constexpr int I = decltype(IC)::value;
+    static_assert(NBUF == 2 || (32 % WAVES) == 0, "counted waits need the same number of pieces in every wave");
+    constexpr int N = SCH::template in_flight<NBUF>(I);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     __syncthreads();
-    if (pi + 1 < NPAN) dma(pi + 1);
-    const unsigned char* p = pan + (pi & 1) * TB_PANEL_BYTES;
-    ++pi;
-    return p;
+    dma(std::integral_constant<int, I + NBUF - 1>{});
+    return pan_lds + (I % TB_NBUF) * TB_PANEL_BYTES;
   };
 
-  dma(0);
-  for (int i = t; i < TC_N; i += 512) cst[i] = a.consts[i];
+  tb_static_for<0, NBUF - 1>([&](auto IC) { dma(IC); });
+  for (int i = t; i < TC_N; i += WAVES * 64) cst[i] = a.consts[i];
   if (MODE && t < 256) ksm[t] = a.ksum[(size_t)b * 256 + t];
 
   // ---- X: the input rows, split (mode 0: hidden; mode 1: D)
@@ -343,14 +433,15 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  if (MODE) {
+  constexpr int P0 = MODE ? 16 : 0;  // first panel of the common part
+  if constexpr (MODE != 0) {
     // ---- q = D Wq^T + b, focus, z
     zero_acc();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned char* p = next_panel();
+    tb_static_for<0, 8>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const unsigned p = next_panel(std::integral_constant<int, j>{});
       tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg);
-    }
+    });
     {
       const float inv = cst[TC_SC + 0] * (1.0f / sx);
       float n1 = 0.f, n3 = 0.f;
@@ -390,11 +481,11 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
     }
     // ---- hidden_h = phi(q)_h kv_h  (K = 64 per head: k-steps 2h, 2h+1)
     zero_acc();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned char* p = next_panel();
+    tb_static_for<0, 8>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      const unsigned p = next_panel(std::integral_constant<int, 8 + j>{});
       tb_mma<2>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg);
-    }
+    });
     {
       const float inv = a.kvinv[b] * (1.0f / sx);
 #pragma unroll
@@ -407,11 +498,11 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
 
   // ---- y = LayerNorm(hidden Wlin^T + b + residual)
   zero_acc();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const unsigned char* p = next_panel();
+  tb_static_for<0, 8>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const unsigned p = next_panel(std::integral_constant<int, P0 + j>{});
     tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg);
-  }
+  });
   {
     const float inv = cst[TC_SC + 1] * (1.0f / sx);
     const float* rs = (MODE ? a.in : a.resid) + (size_t)row * 256;
@@ -438,12 +529,12 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
   zero_acc();
   {
     const float inv_e = cst[TC_SC + 2] * (1.0f / sy), sh = cst[TC_SC + 4];
-#pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
+    tb_static_for<0, 4>([&](auto CC) {
+      constexpr int c = decltype(CC)::value;
       half8 hh[4], hl[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned char* p = next_panel();
+      tb_static_for<0, 4>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + u>{});
         f32x4 ha[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         tb_mma<8>(ha[0], ha[1], p, xh, xl, fr, fg);
 #pragma unroll
@@ -459,13 +550,13 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
             hl[u][4 * w + r] = (_Float16)(v - (float)hi);
           }
         }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned char* p = next_panel();
+      });
+      tb_static_for<0, 8>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + 4 + j>{});
         tb_mma<4>(acc[2 * j], acc[2 * j + 1], p, hh, hl, fr, fg);
-      }
-    }
+      });
+    });
   }
   {
     const float inv = cst[TC_SC + 3], isy = 1.0f / sy;
@@ -489,18 +580,38 @@ __global__ __launch_bounds__(512) void token_block_kernel(TbArgs a) {
   }
 }
 
-#define TB_LDS_BYTES (2 * TB_PANEL_BYTES + (TC_N + 256) * 4)
+#define TB_LDS_BYTES(NBUF) ((NBUF) * TB_PANEL_BYTES + (TC_N + 256) * 4)
+
+// Two shapes of the same kernel: 4 waves x 16 tokens with a 2-slot panel ring (77 KB of LDS: two workgroups per CU, which run out
+// of step, so one's row epilogues overlap the other's MFMAs), and 8 waves x 16 tokens with a 4-slot ring (one workgroup per CU).
+// SAM6D_BLOCK_SHAPE=8 selects the latter (kept for A/B measurements).
+static int tb_shape() {
+  static int shape = 0;
+  if (!shape) {
+    const char* e = getenv("SAM6D_BLOCK_SHAPE");
+    shape = (e && e[0] == '8') ? 8 : 4;
+  }
+  return shape;
+}
+
+template <class K>
+static int tb_attr(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    sam6d_set_error("token_block: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
 
 static int tb_set_attr() {
   static bool done0 = false;
   if (!done0) {
-    hipError_t e = hipFuncSetAttribute((const void*)token_block_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)token_block_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES);
-    if (e != hipSuccess) {
-      sam6d_set_error("token_block: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return (int)e;
-    }
+    int rc = tb_attr(token_block_kernel<0, 4, 2>, TB_LDS_BYTES(2));
+    if (!rc) rc = tb_attr(token_block_kernel<1, 4, 2>, TB_LDS_BYTES(2));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 8, 4>, TB_LDS_BYTES(4));
+    if (!rc) rc = tb_attr(token_block_kernel<1, 8, 4>, TB_LDS_BYTES(4));
+    if (rc) return rc;
     done0 = true;
   }
   return 0;
@@ -514,7 +625,10 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   int rc = tb_set_attr();
   if (rc) return rc;
   TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps};
-  hipLaunchKernelGGL(token_block_kernel<0>, dim3((unsigned)((M + TB_TOK - 1) / TB_TOK)), dim3(512), TB_LDS_BYTES, (hipStream_t)stream, a);
+  if (tb_shape() == 8)
+    hipLaunchKernelGGL((token_block_kernel<0, 8, 4>), dim3((unsigned)((M + 127) / 128)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((token_block_kernel<0, 4, 2>), dim3((unsigned)((M + 63) / 64)), dim3(256), TB_LDS_BYTES(2), (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("token_block");
 }
 
@@ -526,9 +640,13 @@ extern "C" int sam6d_linattn_layer(const float* D, const void* wimage, const flo
   if (B == 0) return 0;
   int rc = tb_set_attr();
   if (rc) return rc;
-  const int tiles = (I - row0 + TB_TOK - 1) / TB_TOK;
+  const int tok = 16 * tb_shape();
+  const int tiles = (I - row0 + tok - 1) / tok;
   SAM6D_REQUIRE((long)B * tiles < 2147483647L, "linattn_layer: too many tiles");
   TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps};
-  hipLaunchKernelGGL(token_block_kernel<1>, dim3((unsigned)(B * tiles)), dim3(512), TB_LDS_BYTES, (hipStream_t)stream, a);
+  if (tb_shape() == 8)
+    hipLaunchKernelGGL((token_block_kernel<1, 8, 4>), dim3((unsigned)(B * tiles)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((token_block_kernel<1, 4, 2>), dim3((unsigned)(B * tiles)), dim3(256), TB_LDS_BYTES(2), (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("linattn_layer");
 }

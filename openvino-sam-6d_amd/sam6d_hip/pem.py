@@ -39,7 +39,7 @@ class Linear:
         self.w, self.b = w.contiguous(), (b.contiguous() if b is not None else None)
 
 
-TB_P256, TB_P128, TB_P64 = 33 * 1024, 17 * 1024, 9 * 1024  # panel bytes of csrc/block.hip (32 rows x K = 256 / 128 / 64)
+TB_P256, TB_P128, TB_P64 = 32768, 16384, 8192  # panel bytes of csrc/block.hip (32 rows x K = 256 / 128 / 64, fp16 hi + lo)
 TB_CHUNK = 4 * TB_P256 + 8 * TB_P128
 TB_Q_OFF = 8 * TB_P256 + 4 * TB_CHUNK
 
