@@ -676,6 +676,32 @@ def compute_fine_Rt(att, pts1, pts2, model, radius, dis_thres=0.15):
     return R, t, score
 
 
+def fine_match(f, B, n, temp, pts2):
+    """f (2B*n, 256) out_proj outputs [scene clouds; template clouds] -> label1, label2 (B,n-1) i32, pred (B,n-1,3), weight (B,n-1)
+    (compute_feature_similarity + the soft-assignment head of compute_fine_Rt, PEM/utils/model_utils.py:131-153, 308-331)."""
+    l1 = _empty((B, n - 1), f, torch.int32)
+    l2 = _empty((B, n - 1), f, torch.int32)
+    pred = _empty((B, n - 1, 3), f)
+    wgt = _empty((B, n - 1), f)
+    nbytes = int(_lib.load().sam6d_fine_match_workspace_bytes(B))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
+    with _Timed("fine_match"):
+        _lib.call("sam6d_fine_match", _p(f), B, n, float(temp), _p(pts2), _p(l1), _p(l2), _p(pred), _p(wgt), ws.data_ptr(), nbytes, _s())
+    return l1, l2, pred, wgt
+
+
+def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.15):
+    """compute_feature_similarity + compute_fine_Rt (PEM/utils/model_utils.py:131-153, 308-341) from the out_proj features."""
+    pts2 = pts2.contiguous()
+    l1, l2, pred, wgt = fine_match(f, B, n, temp, pts2)
+    R, t = weighted_procrustes(pred, pts1, wgt, 0.0)
+    cnt = _empty((B, 2), f)
+    score = _empty((B,), f)
+    _lib.call("sam6d_fine_score", _p(pts1), _p(R), _p(t), _p(model), _p(radius), _p(l1), B, n - 1, model.shape[1], float(dis_thres),
+              _p(cnt), _p(score), _s())
+    return R, t, score
+
+
 # --------------------------------------------------------------------------------------------------- modules
 def sample_pts_feats(pts, feats, npoint):
     """PEM/utils/model_utils.py:70-84 on (B',N,3) / (B',N,C): FPS + two row gathers."""
@@ -756,6 +782,10 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
                             cfg["pe_nsample2"])
     for blk in W.fine["blocks"]:
         D = sparse_to_dense_transformer(D, E, fps_idx, blk)
+    if not return_aux and N == 2048 and _fused_block():
+        # similarity + soft assignment as one pipeline: the (B, 2049, 2049) matrix is written once and read twice (finematch.hip)
+        f = linear(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"])
+        return compute_fine_Rt_fused(f, B, N + 1, cfg["temp"], dp[:B], dp[B:], model, radius, cfg["dis_thres"])
     att = feature_similarity(D, B, N + 1, W.fine["out_proj"], cfg["temp"])
     R, t, score = compute_fine_Rt(att, dp[:B], dp[B:], model, radius, cfg["dis_thres"])
     if return_aux:

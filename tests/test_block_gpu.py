@@ -119,3 +119,70 @@ def test_linattn_layer_vs_oracle_math(dev, Bp, I, qs):
     assert torch.isfinite(got).all()
     err = float((got - want).abs().max())
     assert err < 5e-5, "dense linear-attention layer vs fp64: %.3e" % err
+
+
+# ------------------------------------------------------------------------------------- fine similarity + soft assignment pipeline
+def _fine_match_oracle(F, B, temp, pts2):
+    """compute_feature_similarity + the head of compute_fine_Rt on the CPU (oracle/pem_oracle.py restates model_utils.py:131-153, 308-331)."""
+    from oracle import pem_oracle as O
+    n = F.shape[1]
+    f1 = torch.nn.functional.normalize(F[:B], dim=2)
+    f2 = torch.nn.functional.normalize(F[B:], dim=2)
+    att = f1 @ f2.transpose(1, 2) / temp
+    S, l1, l2 = O.soft_assignment(att)
+    A = S[:, 1:, 1:] * (l1 > 0).float().unsqueeze(2) * (l2 > 0).float().unsqueeze(1)
+    w = A.sum(2)
+    pred = (A / (w.unsqueeze(2) + 1e-6)) @ pts2
+    return att, l1, l2, w, pred
+
+
+@pytest.mark.parametrize("kind", ["matched", "flat"])
+def test_fine_match_pipeline_vs_oracle(dev, kind):
+    """sam6d_fine_match (finematch.hip) against the oracle.  `matched`: every scene feature is a noisy copy of one template feature (a
+    third of them of the bg token), so the arg-max labels are well separated and must be bit-exact; `flat`: unrelated random features
+    (a nearly uniform assignment matrix whose arg-max is decided in the last bits): >= 99.5 % of the labels, weights / targets to 1e-5."""
+    from sam6d_hip import pem
+    gen = torch.Generator().manual_seed(3 if kind == "matched" else 4)
+    B, n = 2, 2049
+    F = torch.randn(2 * B, n, 256, generator=gen)
+    if kind == "matched":
+        perm = torch.stack([torch.randperm(n, generator=gen) for _ in range(B)])
+        for b in range(B):
+            src = F[B + b][perm[b]]
+            src[::3] = F[B + b][0]  # a third of the scene points look like the template's bg token
+            F[b] = src + 0.25 * torch.randn(n, 256, generator=gen)
+    pts2 = torch.rand(B, n - 1, 3, generator=gen) - 0.5
+    att, l1, l2, w, pred = _fine_match_oracle(F, B, 0.1, pts2)
+    gl1, gl2, gpred, gw = pem.fine_match(F.reshape(-1, 256).to(dev).contiguous(), B, n, 0.1, pts2.to(dev).contiguous())
+    n1 = int((gl1.cpu() != l1.to(torch.int32)).sum()); n2 = int((gl2.cpu() != l2.to(torch.int32)).sum())
+    print("\\n[%s] label mismatches: rows %d, columns %d of %d; fg rows %d" % (kind, n1, n2, l1.numel(), int((l1 > 0).sum())))
+    if kind == "matched":
+        assert n1 == 0 and n2 == 0
+        assert 0 < int((l1 > 0).sum()) < l1.numel() and 0 < int((l2 > 0).sum())
+        assert float((gw.cpu() - w).abs().max()) < 1e-5 and float((gpred.cpu() - pred).abs().max()) < 1e-5
+    else:
+        assert n1 <= 0.005 * l1.numel() and n2 <= 0.005 * l2.numel()
+        same = ((gl1.cpu() == l1.to(torch.int32)) & (l1 > 0)) | ((gl1.cpu() == 0) & (l1 == 0))
+        assert float((gw.cpu() - w).abs()[same].max()) < 1e-5
+
+
+def test_fine_match_equals_unfused_path(dev):
+    """same features through the launch-per-op path (l2norm, GEMM, sam6d_soft_assign, sam6d_fine_assign) and the pipeline"""
+    from sam6d_hip import pem
+    gen = torch.Generator().manual_seed(8)
+    B, n = 3, 2049
+    F = torch.randn(2 * B, n, 256, generator=gen)
+    perm = torch.randperm(n, generator=gen)
+    F[:B] = F[B:, perm] + 0.3 * torch.randn(B, n, 256, generator=gen)
+    pts1 = (torch.rand(B, n - 1, 3, generator=gen) - 0.5).to(dev)
+    pts2 = (torch.rand(B, n - 1, 3, generator=gen) - 0.5).to(dev)
+    model = (torch.rand(B, 512, 3, generator=gen) - 0.5).to(dev)
+    radius = torch.ones(B, device=dev)
+    Fd = F.to(dev)
+    f = Fd.reshape(-1, 256).clone()
+    pem._lib.call("sam6d_l2norm256", f.data_ptr(), f.data_ptr(), 2 * B * n, 256, 256, torch.cuda.current_stream().cuda_stream)
+    att = torch.empty(B, n, n, device=dev)
+    pem.gemm(f, f, None, att, n, n, 256, 256, 256, n, w_off=B * n * 256, batch=B, sA=n * 256, sW=n * 256, sC=n * n, divisor=0.1)
+    Ra, ta, sa = pem.compute_fine_Rt(att, pts1, pts2, model, radius)
+    Rb, tb, sb = pem.compute_fine_Rt_fused(Fd.reshape(-1, 256).contiguous(), B, n, 0.1, pts1, pts2, model, radius)
+    assert float((Ra - Rb).abs().max()) < 1e-5 and float((ta - tb).abs().max()) < 1e-5 and float((sa - sb).abs().max()) < 1e-5
