@@ -209,6 +209,7 @@ __device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, unsigned panel,
   tb_u32x4 f[TB_FD + 1][4];
   tb_load_step<KS, 0>(a, f[0]);
   if constexpr (TB_FD >= 2 && KS >= 2) tb_load_step<KS, 1>(a, f[1]);
+  if constexpr (TB_FD >= 3 && KS >= 3) tb_load_step<KS, 2>(a, f[2]);
   tb_mma_step<KS, 0>(acc0, acc1, a, xh, xl, f);
 }
 
