@@ -35,6 +35,10 @@ int sam6d_abi_version(void);
  * (EXT/src/sampling.cpp:184-212; loop :76-118).  xyz (B,N,3) f32 -> idx (B,m) i32.
  * temp: (B,N) f32 scratch, required only when N > 4096 (the reference allocates the same `tmp`, :192-194). */
 int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int* idx, void* stream);
+/* Test hook of the multi-workgroup FPS (N > 4096; EXT/src/sampling.cpp:76-118 is the loop it replaces): the number of polls a
+ * workgroup waits at the grid-wide arg-max of a round before it gives the cloud up to the one-workgroup kernel queued behind it
+ * (cap < 0: the default, 2^24; 0: give up at once).  Results are identical on both paths. */
+int sam6d_fps_debug_spin_cap(long cap);
 
 /* replaces `at::Tensor gather_points(at::Tensor points, at::Tensor idx)` (EXT/src/sampling.cpp:120-150; loop :23-44).
  * points (B,C,N) f32, idx (B,M) i32 -> out (B,C,M) f32; out-of-range index -> 0. */
@@ -82,7 +86,12 @@ int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int
 
 /* Matrix-core arithmetic of gemm_nt / geo_embed: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
  * 1 = fp16 x3 split (x = hi + lo in fp16, 3 MFMAs, ~1e-6 relative; default).  Both replace the same F.linear call
- * sites (PEM/model/transformer.py:127-129); the mode is process-wide. */
+ * sites (PEM/model/transformer.py:127-129); the mode is process-wide.
+ * Operand range in mode 1: ANY finite fp32 input is accepted.  sam6d_gemm_nt keeps the split for tiles whose operands lie in
+ * [2^-6, 2^15) in magnitude (by their tile maximum; what the matching path produces itself is always there) and recomputes a tile
+ * whose A or W block leaves that range with the exact fp32 MFMA loop of mode 0, so |x| >= 65520 cannot become inf - inf and uniformly
+ * tiny operands do not lose their fp16 lo halves; the fused block kernels (sam6d_token_block, sam6d_linattn_layer,
+ * sam6d_fine_match) scale every operand row / matrix by a power of two instead (exact to undo). */
 int sam6d_set_matmul_mode(int mode);
 int sam6d_get_matmul_mode(void);
 

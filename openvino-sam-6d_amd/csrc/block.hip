@@ -606,14 +606,13 @@ static int tb_attr(K kernel, int bytes) {
 }
 
 static int tb_set_attr() {
-  static bool done0 = false;
-  if (!done0) {
+  static unsigned long long done0 = 0;
+  if (sam6d_first_use_on_device(&done0)) {
     int rc = tb_attr(token_block_kernel<0, 4, 2>, TB_LDS_BYTES(2));
     if (!rc) rc = tb_attr(token_block_kernel<1, 4, 2>, TB_LDS_BYTES(2));
     if (!rc) rc = tb_attr(token_block_kernel<0, 8, 4>, TB_LDS_BYTES(4));
     if (!rc) rc = tb_attr(token_block_kernel<1, 8, 4>, TB_LDS_BYTES(4));
     if (rc) return rc;
-    done0 = true;
   }
   return 0;
 }

@@ -160,3 +160,17 @@ __device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// One-time per-DEVICE setup (hipFuncSetAttribute, CU count ...): `done` is a bit mask over device ordinals owned by the call site;
+// returns true the first time the calling thread's current device is seen.  A process that drives several GPUs gets every device
+// initialised, instead of device 0's state being reused for all of them.
+static inline bool sam6d_first_use_on_device(unsigned long long* done, int* dev_out = nullptr) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev_out) *dev_out = dev;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*done & bit) return false;
+  *done |= bit;
+  return true;
+}
+#define SAM6D_MAX_DEVICES 64

@@ -60,28 +60,16 @@ __device__ __forceinline__ bool gemm_tile(int M, int N, const Batch2& b2, int& z
   return true;
 }
 
+// Exact fp32 main loop of one BM x BN tile (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain).  Shared by gemm_nt_kernel and by the
+// split-precision kernel's out-of-range fallback.  As / Bs: BM x GM_LD and BN x GM_LD floats of LDS.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                      const float* __restrict__ bias, const float* __restrict__ colscale,
-                                                      const float* __restrict__ residual, float* __restrict__ C, int M, int N,
-                                                      int K, long lda, long ldw, long ldc, long ldr, long sA, long sW, long sC,
-                                                      long sR, float divisor, int act, Batch2 b2) {
+__device__ __forceinline__ void gemm_exact_mainloop(f32x16 (&acc)[BM / 64][BN / 64], const float* __restrict__ A,
+                                                    const float* __restrict__ W, int M, int N, int K, long lda, long ldw, int m0,
+                                                    int n0, float* __restrict__ As, float* __restrict__ Bs) {
   constexpr int TM = BM / 64, TN = BN / 64;  // MFMA tiles per wave
   constexpr int RA = BM / 64, RB = BN / 64;  // float4 staging loads per thread
-  __shared__ float As[BM * GM_LD];
-  __shared__ float Bs[BN * GM_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int zz, tm_, tn_;
-  if (!gemm_tile<BM, BN>(M, N, b2, zz, tm_, tn_)) return;  // padding workgroup (uniform)
-  const int bz = zz / b2.n2, bi = zz % b2.n2;
-  A += (size_t)bz * sA + (size_t)bi * b2.sA2;
-  W += (size_t)bz * sW + (size_t)bi * b2.sW2;
-  C += (size_t)bz * sC + (size_t)bi * b2.sC2;
-  if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
-  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-
-  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -152,6 +140,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ colscale,
+                                                      const float* __restrict__ residual, float* __restrict__ C, int M, int N,
+                                                      int K, long lda, long ldw, long ldc, long ldr, long sA, long sW, long sC,
+                                                      long sR, float divisor, int act, Batch2 b2) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // MFMA tiles per wave
+  constexpr int RA = BM / 64, RB = BN / 64;  // float4 staging loads per thread
+  __shared__ float As[BM * GM_LD];
+  __shared__ float Bs[BN * GM_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int zz, tm_, tn_;
+  if (!gemm_tile<BM, BN>(M, N, b2, zz, tm_, tn_)) return;  // padding workgroup (uniform)
+  const int bz = zz / b2.n2, bi = zz % b2.n2;
+  A += (size_t)bz * sA + (size_t)bi * b2.sA2;
+  W += (size_t)bz * sW + (size_t)bi * b2.sW2;
+  C += (size_t)bz * sC + (size_t)bi * b2.sC2;
+  if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+
+  f32x16 acc[TM][TN];
+  gemm_exact_mainloop<BM, BN>(acc, A, W, M, N, K, lda, ldw, m0, n0, As, Bs);
+  const int fr = lane & 31, fk = lane >> 5;
   // epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -272,11 +286,13 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   };
 
   const int fr = lane & 31, fk = lane >> 5;
+  float ma = 0.f, mw = 0.f;  // running max |A|, max |W| of what this thread stages (range check below)
   fetch(0);
   for (int k0 = 0; k0 < K; k0 += H_BK) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < RA; ++u) {
+      ma = fmaxf(fmaxf(ma, fabsf(va[u].x)), fmaxf(fabsf(va[u].y), fmaxf(fabsf(va[u].z), fabsf(va[u].w))));
       half4 hi, lo;
       split4(va[u], hi, lo);
       *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
@@ -284,6 +300,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
+      mw = fmaxf(fmaxf(mw, fabsf(vb[u].x)), fmaxf(fabsf(vb[u].y), fmaxf(fabsf(vb[u].z), fabsf(vb[u].w))));
       half4 hi, lo;
       split4(vb[u], hi, lo);
       *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
@@ -312,6 +329,28 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+    }
+  }
+  // ---- range of the fp16 split.  x = hi + lo carries 22 significand bits only while hi cannot overflow (|x| < 65520) and lo is not
+  // pushed far into fp16's subnormals (|x| well above 2^-14 * 2^11).  A tile whose operands leave [2^-6, 2^15) -- raw features of an
+  // unknown checkpoint, unnormalised descriptors -- is recomputed here with the exact fp32 MFMA loop of gemm_nt_kernel, which has
+  // fp32's own range; in-range tiles (everything the matching path produces itself) are untouched, so results stay independent of the
+  // batch neighbours that share a tile.  All-zero operands are left alone.
+  {
+    ma = wave_max_dpp(ma);
+    mw = wave_max_dpp(mw);
+    __syncthreads();  // the staging buffers are free
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) { red[wave] = ma; red[4 + wave] = mw; }
+    __syncthreads();
+    const float ta = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float tw = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const bool bad = !(ta < 32768.0f) || !(tw < 32768.0f) || (ta > 0.f && ta < 0.015625f) || (tw > 0.f && tw < 0.015625f);
+    __syncthreads();
+    if (bad) {  // (uniform for the workgroup)
+      float* As = reinterpret_cast<float*>(smem);
+      gemm_exact_mainloop<BM, BN>(acc, A, W, M, N, K, lda, ldw, m0, n0, As, As + BM * GM_LD);
+      __syncthreads();
     }
   }
   if (wide) {

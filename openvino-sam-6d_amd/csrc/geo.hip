@@ -360,15 +360,14 @@ extern "C" int sam6d_split_f16(const float* x, long n, float scale, void* hi, vo
 }
 
 static int h3_reserve_lds() {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;
+  if (sam6d_first_use_on_device(&attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_embed_h3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GH_LDS_BYTES);
     if (e != hipSuccess) {
       sam6d_set_error("geo_embed_h3: cannot reserve %d bytes of LDS: %s", GH_LDS_BYTES, hipGetErrorString(e));
       return (int)e;
     }
-    attr_set = true;
   }
   return 0;
 }
@@ -585,20 +584,22 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
                 "geo_embed_cheb: idx_ws/weights must be 16-byte aligned");
   if (pairs == 0) return 0;
   if (int rc = h3_reserve_lds()) return rc;
-  static int n_cu = 0;
-  if (n_cu == 0) {
+  static int n_cu_dev[SAM6D_MAX_DEVICES];
+  static unsigned long long cheb_done = 0;
+  int dev = 0;
+  if (sam6d_first_use_on_device(&cheb_done, &dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_cheb_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS_BYTES);
-    int dev = 0, cu = 0;
-    if (e == hipSuccess) e = hipGetDevice(&dev);
+    int cu = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cu <= 0) {
       sam6d_set_error("geo_embed_cheb: cannot reserve %d bytes of LDS / query the device: %s", GC_LDS_BYTES,
                       hipGetErrorString(e));
       return e != hipSuccess ? (int)e : SAM6D_EINVAL;
     }
-    n_cu = cu;
+    n_cu_dev[dev & 63] = cu;
   }
+  const int n_cu = n_cu_dev[dev & 63];
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,

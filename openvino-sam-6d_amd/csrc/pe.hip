@@ -322,15 +322,14 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
   if (sam6d_get_matmul_mode() == 1) {
     SAM6D_REQUIRE(total < (1l << 31) / 64, "pe_mlp_max: B*N too large for 32-bit point ids (%ld)", total);
     const size_t lds = (size_t)PH_WBYTES;
-    static bool attr_h3 = false;
-    if (!attr_h3) {
+    static unsigned long long attr_h3 = 0;
+    if (sam6d_first_use_on_device(&attr_h3)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_h3_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) {
         sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
         return (int)e;
       }
-      attr_h3 = true;
     }
     // persistent waves: 3 workgroups of 4 waves fit one CU's LDS (3 x 48.6 KB) -> 768 workgroups fill the 256 CUs once
     const long want = (total + PH_WAVES - 1) / PH_WAVES;
@@ -339,15 +338,14 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
                        W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
   } else {
     const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (sam6d_first_use_on_device(&attr_set)) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pe_mlp_max_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) {
         sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
         return (int)e;
       }
-      attr_set = true;
     }
     hipLaunchKernelGGL(pe_mlp_max_kernel, grid, dim3(PM_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, total, W1, sc1,
                        sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);

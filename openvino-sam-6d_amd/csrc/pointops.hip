@@ -92,15 +92,27 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
 // Large-N variant (e.g. the 210 000-point template cloud of get_obj_feats, PEM/model/feature_extraction.py:152-158):
 // running min-distances live in a global scratch row (`temp`, the same (B,N) buffer the reference allocates and never
 // uses on CPU, sampling.cpp:192-194); points are re-read from global/L2 each round.  Same selection rule.
+// `gate` != 0: the launch is the fallback behind fps_grid_kernel -- cloud b is recomputed only if that kernel raised its abort word
+// (the first 64-bit word of fps_grid_ws(temp, b, N), inside this cloud's own scratch row, so no other workgroup can overwrite it).
+__device__ __forceinline__ unsigned long long* fps_grid_ws(float* temp, int b, int N) {
+  return reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(temp + (size_t)b * N) + 7) & ~(uintptr_t)7);
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void fps_big_kernel(const float* __restrict__ xyz, int N, int m,
-                                                         float* __restrict__ temp, int* __restrict__ out) {
+                                                         float* __restrict__ temp, int* __restrict__ out, int gate) {
   constexpr int NW = THREADS / 64;
   __shared__ unsigned long long slots[2][NW];
+  __shared__ unsigned long long s_gate;
   const int b = blockIdx.x, t = threadIdx.x;
   const float* p = xyz + (size_t)b * N * 3;
   float* td = temp + (size_t)b * N;
   int* o = out + (size_t)b * m;
+  if (gate) {
+    if (t == 0) s_gate = __hip_atomic_load(fps_grid_ws(temp, b, N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_gate == 0ull) return;  // the grid kernel finished this cloud
+  }
   for (int k = t; k < N; k += THREADS) td[k] = FLT_MAX;
   if (t == 0) o[0] = 0;
   int last = 0;
@@ -142,20 +154,22 @@ __global__ __launch_bounds__(THREADS) void fps_big_kernel(const float* __restric
 // ws per cloud: m round slots + arrival counter + abort flag (64-bit each), zeroed by the host before the launch.
 // Co-residency: the host launches at most FPS_GRID_MAX_WG workgroups (one 256-thread workgroup per CU always fits
 // beside whatever else is running, and nothing ever waits on this kernel), and the spin has a bounded exit: a workgroup
-// that waits longer than FPS_SPIN_CAP polls raises the abort flag, every workgroup leaves, and out[b][m-1] is set to -1.
+// that waits longer than the spin cap raises the cloud's abort word and every workgroup of that cloud leaves; the host always
+// queues the one-workgroup kernel behind this one, gated on that word, so an aborted cloud is recomputed (slowly) instead of
+// being returned truncated.  The grid is also checked against the occupancy API before this path is chosen.
 #define FPS_GRID_MAX_WG 256
 #define FPS_SPIN_CAP (1u << 24)
 template <int PPT>
-__global__ __launch_bounds__(256) void fps_grid_kernel(const float* __restrict__ xyz, int N, int m,
-                                                      unsigned long long* __restrict__ ws, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void fps_grid_kernel(const float* __restrict__ xyz, int N, int m, float* __restrict__ temp,
+                                                      int* __restrict__ out, unsigned spin_cap) {
   __shared__ unsigned long long slots[2][4];
   __shared__ unsigned long long s_best;
   const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, t = threadIdx.x;
   const float* p = xyz + (size_t)b * N * 3;
   int* o = out + (size_t)b * m;
-  unsigned long long* best = ws + (size_t)b * (m + 2);
-  unsigned long long* arrived = best + m;
-  unsigned long long* abort_flag = best + m + 1;
+  unsigned long long* abort_flag = fps_grid_ws(temp, b, N);  // [abort | arrived | best[0 .. m)]: zeroed by fps_grid_zero_kernel
+  unsigned long long* arrived = abort_flag + 1;
+  unsigned long long* best = abort_flag + 2;
   float px[PPT], py[PPT], pz[PPT], td[PPT];
   bool live[PPT];
 #pragma unroll
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void fps_grid_kernel(const float* __restrict__
       unsigned int polls = 0;
       bool dead = false;
       while (__hip_atomic_load(arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || ++polls > FPS_SPIN_CAP) {
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || ++polls > spin_cap) {
           __hip_atomic_store(abort_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           dead = true;
           break;
@@ -214,13 +228,23 @@ __global__ __launch_bounds__(256) void fps_grid_kernel(const float* __restrict__
     }
     __syncthreads();
     const unsigned long long win = s_best;
-    if (win == ~0ull) {  // aborted (~0 is no valid key: the distance field would be a NaN pattern)
-      if (g == 0 && t == 0) o[m - 1] = -1;
-      return;
-    }
+    if (win == ~0ull) return;  // aborted (~0 is no valid key: the distance field would be a NaN pattern); the gated fps_big_kernel
+                               // launched right behind this kernel recomputes the cloud
     last = (win == 0ull) ? 0 : (int)(~(unsigned int)(win & 0xffffffffull));
     if (g == 0 && t == 0) o[j] = last;
   }
+}
+
+__global__ __launch_bounds__(256) void fps_grid_zero_kernel(float* __restrict__ temp, int N, int m) {
+  unsigned long long* w = fps_grid_ws(temp, blockIdx.x, N);
+  for (int i = threadIdx.x; i < m + 2; i += 256) w[i] = 0ull;
+}
+
+static unsigned g_fps_spin_cap = FPS_SPIN_CAP;
+// test hook: polls a workgroup of the multi-workgroup FPS waits for the others before it gives the cloud up (0 = at once)
+extern "C" int sam6d_fps_debug_spin_cap(long cap) {
+  g_fps_spin_cap = cap < 0 ? FPS_SPIN_CAP : (unsigned)cap;
+  return 0;
 }
 
 extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int m, float* temp, int* idx,
@@ -237,17 +261,26 @@ extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int
   } else {
     SAM6D_REQUIRE(temp, "furthest_point_sampling: N=%d > 4096 needs the (B,N) float scratch `temp`", N);
     const long G = ((long)N + 1023) / 1024;  // 256 threads x 4 points per workgroup
-    const size_t ws_bytes = (size_t)B * (m + 2) * 8;
-    if (G * B <= FPS_GRID_MAX_WG && ws_bytes <= (size_t)B * N * 4 && ((uintptr_t)temp & 7) == 0) {
-      hipError_t e = hipMemsetAsync(temp, 0, ws_bytes, s);  // round slots, arrival counter, abort flag
-      if (e != hipSuccess) {
-        sam6d_set_error("furthest_point_sampling: hipMemsetAsync failed: %s", hipGetErrorString(e));
-        return (int)e;
-      }
-      hipLaunchKernelGGL((fps_grid_kernel<4>), dim3((unsigned)G, B), dim3(256), 0, s, xyz, N, m,
-                         reinterpret_cast<unsigned long long*>(temp), idx);
+    // co-residency of the hand-rolled grid barrier: all G * B workgroups must fit on the chip at once
+    static int resident_dev[SAM6D_MAX_DEVICES];
+    static unsigned long long resident_done = 0;
+    int dev = 0;
+    if (sam6d_first_use_on_device(&resident_done, &dev)) {
+      int cu = 0, per_cu = 0;
+      hipError_t e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_grid_kernel<4>, 256, 0);
+      resident_dev[dev & 63] = (e == hipSuccess && cu > 0 && per_cu > 0) ? cu * (per_cu > 1 ? per_cu - 1 : 1) : 0;  // (margin: the API can be one high)
+      (void)hipGetLastError();
+    }
+    const int max_resident = resident_dev[dev & 63];
+    const long cap_wg = max_resident < FPS_GRID_MAX_WG ? max_resident : FPS_GRID_MAX_WG;
+    const bool grid_ok = G * B <= cap_wg && (size_t)(m + 2) * 8 + 8 <= (size_t)N * 4;  // the round slots live in the cloud's own row
+    if (grid_ok) {
+      hipLaunchKernelGGL(fps_grid_zero_kernel, dim3(B), dim3(256), 0, s, temp, N, m);
+      hipLaunchKernelGGL((fps_grid_kernel<4>), dim3((unsigned)G, B), dim3(256), 0, s, xyz, N, m, temp, idx, g_fps_spin_cap);
+      hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx, 1);  // runs only for aborted clouds
     } else {
-      hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx);
+      hipLaunchKernelGGL((fps_big_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, N, m, temp, idx, 0);
     }
   }
   SAM6D_LAUNCH_CHECK("furthest_point_sampling");

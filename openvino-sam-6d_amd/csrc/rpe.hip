@@ -341,19 +341,21 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
                 "rpe_scores: idx_ws / wa_cheb / qp / qd / rows must be 16-byte aligned");
   if (Q == 0) return 0;
   const int lds_max = 160 * 1024;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, cu = 0;
+  static int n_cu_dev[SAM6D_MAX_DEVICES];
+  static unsigned long long rpe_done = 0;
+  int dev = 0;
+  if (sam6d_first_use_on_device(&rpe_done, &dev)) {
+    int cu = 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-    if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cu <= 0) {
       sam6d_set_error("rpe_scores: cannot reserve %d bytes of LDS / query the device: %s", lds_max, hipGetErrorString(e));
       return e != hipSuccess ? (int)e : SAM6D_EINVAL;
     }
-    n_cu = cu;
+    n_cu_dev[dev & 63] = cu;
   }
+  const int n_cu = n_cu_dev[dev & 63];
   const float scale = 0.125f;  // 1/sqrt(64): d_model 256, 4 heads (coarse_point_matching.py:24, fine_point_matching.py:31)
   const int mpad = ((n + 15) / 16) * 16;
   const int per_wave = (RP_QW_FLOATS + 4 * mpad) * 4;

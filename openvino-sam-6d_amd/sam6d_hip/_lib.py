@@ -18,6 +18,7 @@ c_p = ctypes.c_void_p
 # and checks that every declared symbol is exported and listed here.
 SIGNATURES = {
     "sam6d_furthest_point_sampling": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_fps_debug_spin_cap": [c_l],
     "sam6d_gather_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_ball_query": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
     "sam6d_ball_query2": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_f, c_i, c_p, c_p],

@@ -4,11 +4,12 @@ compute_geometric_score and model.loss.*  (ISM = SAM-6D/Instance_Segmentation_Mo
 import torch
 
 from . import _lib
-from .pem import _empty, _p, _s, gemm
+from .pem import _empty, _p, _s, gemm, on_tensor_device
 
 _MODES = {"avg_5": 0, "mean": 1, "max": 2}
 
 
+@on_tensor_device
 def pairwise_similarity(query, reference):
     """ISM/model/loss.py:27-44: query (Nq,D), reference (No,Nt,D) -> (Nq,No,Nt) in [0,1]."""
     Nq, D = query.shape
@@ -18,6 +19,7 @@ def pairwise_similarity(query, reference):
     return out
 
 
+@on_tensor_device
 def semantic_select(scores, aggregation="avg_5", confidence_thresh=0.2):
     """ISM/model/detector.py:265-296 on precomputed scores (Nq,No,Nt).
     Returns idx_selected (K,) i64, pred_idx_objects (K,) i64, semantic_score (K,), best_template (K,) i64.
@@ -37,6 +39,7 @@ def semantic_select(scores, aggregation="avg_5", confidence_thresh=0.2):
     return sel, obj.long()[sel], sem[sel], best.long()[sel]
 
 
+@on_tensor_device
 def patch_similarity(q_appe, ref_sel):
     """sim (Ns,P,P) = q_appe (Ns,P,D) @ ref_sel (Ns,P,D)^T on the matrix cores (ISM/model/loss.py:54,66)."""
     Ns, P, D = q_appe.shape
@@ -45,6 +48,7 @@ def patch_similarity(q_appe, ref_sel):
     return sim
 
 
+@on_tensor_device
 def patch_scores(sim, q_appe, thred=0.5):
     """appearance score (loss.py:52-62) and visible ratio (loss.py:64-76) from one similarity tensor."""
     Ns, P, D = q_appe.shape
@@ -54,6 +58,7 @@ def patch_scores(sim, q_appe, thred=0.5):
     return appe, vis
 
 
+@on_tensor_device
 def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale):
     """ISM/model/detector.py:209-246: -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3)."""
     Ns, H, W = masks.shape
@@ -74,6 +79,7 @@ def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, dep
     return vu, xyxy, tr
 
 
+@on_tensor_device
 def compute_iou(xyxy, boxes):
     """ISM/utils/bbox_utils.py:197-222 incl. the quirk: any non-positive overlap => the python float 0.0."""
     Ns = xyxy.shape[0]
@@ -85,6 +91,7 @@ def compute_iou(xyxy, boxes):
     return iou if int(flag.item()) == 1 else 0.0
 
 
+@on_tensor_device
 def final_score(sem, appe, geo, vis):
     """ISM/model/detector.py:384."""
     Ns = appe.shape[0]
@@ -94,6 +101,7 @@ def final_score(sem, appe, geo, vis):
     return out
 
 
+@on_tensor_device
 def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thresh=0.5):
     """CustomDINOv2's descriptor post-processing (ISM/model/dinov2.py:265-269, 322-324): zero the patches whose mask
     coverage (AvgPool2d(patch_size)) is <= validpatch_thresh and L2-normalise the rest.  patch_features (N,P,D),
@@ -112,6 +120,7 @@ def masked_patch_features(patch_features, masks, patch_size=14, validpatch_thres
 
 
 # ------------------------------------------------------------------ Detections bookkeeping (ISM/model/utils.py:84-196)
+@on_tensor_device
 def small_detection_keep(boxes, masks, min_box_size, min_mask_size):
     """ISM/model/utils.py:96-102: bool (N,) -- box area and mask area (as fractions of the image) above the thresholds."""
     from .ops import _chk
@@ -126,6 +135,7 @@ def small_detection_keep(boxes, masks, min_box_size, min_mask_size):
     return keep.bool()
 
 
+@on_tensor_device
 def mask_to_indices(keep):
     """nonzero(keep) as int64 indices (one host read-back of the count, like boolean-mask indexing in torch)."""
     k8 = keep.to(torch.uint8).contiguous()
@@ -136,6 +146,7 @@ def mask_to_indices(keep):
     return idx[: int(cnt.item())]
 
 
+@on_tensor_device
 def take_rows(src, idx):
     """src[idx] for an int64 index vector or a bool mask, any dtype (ISM/model/utils.py:105,119,126,190)."""
     if not src.is_cuda:
@@ -154,6 +165,7 @@ def take_rows(src, idx):
     return out
 
 
+@on_tensor_device
 def nms(boxes, scores, iou_threshold, object_ids=None):
     """torchvision.ops.nms as ISM/model/utils.py:107-126 calls it; with object_ids the per-id variant (ids ascending,
     survivors of each id in descending score order).  Returns int64 indices."""

@@ -23,6 +23,21 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+def on_tensor_device(fn):
+    """Run `fn` with the device of its first tensor argument current: the launches go to torch's current stream OF THAT DEVICE and
+    torch.empty workspaces land there, also when the caller's current device is another GPU of the node."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = next((a.device for a in args if torch.is_tensor(a)), None)
+        if dev is None or dev.type != "cuda":
+            raise RuntimeError("%s: needs HIP device tensors (this build has no CPU path)" % fn.__name__)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 def _p(t, off=0):
     return t.data_ptr() + 4 * off if t is not None else None
 
@@ -313,6 +328,7 @@ class _Timed:
             PROFILE.setdefault(self.name, []).append((self.a, self.b))
 
 
+@on_tensor_device
 def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     """points_bg (B,n,3) with the bg point prepended -> (B,n,n,256)   (PEM/model/transformer.py:343-363)."""
     B, n, _ = points_bg.shape
@@ -398,9 +414,6 @@ class GeoContext:
     """What the fused RPE attention needs instead of the (B,n,n,256) embedding tensor: the per-pair embedding indices, the
     map pair -> stored row for the pairs outside the Chebyshev range, those rows, and the packed coefficient matrices."""
     __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "dcT", "keep")
-
-    def materialize(self, W):
-        raise NotImplementedError
 
 
 def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
@@ -551,6 +564,7 @@ def linear_transformer_layer(D, S, L):
     return _post_attention(hid, D2, L).reshape(Bp, I, C)
 
 
+@on_tensor_device
 def sparse_to_dense_transformer(D, E, fps_idx, T):
     """D (2B,N+1,256) dense tokens incl. bg row, E (2B,n,n,256), fps_idx (2B,n-1) i32 -> new D
     (SparseToDenseTransformer, PEM/model/transformer.py:627-720, incl. the index-into-the-cat quirk :667-705)."""
@@ -590,6 +604,7 @@ def pe_apply(pts, idx12, W, dst, dst_off, dst_sb):
          sC=dst_sb, sR=dst_sb)
 
 
+@on_tensor_device
 def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32, ns2=64):
     """dst[b, 1 + i, :] += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2)))   (PositionalEncoding,
     PEM/model/fine_point_matching.py:102-144).  pts (B',N,3); dst rows addressed by (dst_off, batch stride dst_sb)."""
@@ -616,6 +631,7 @@ def soft_assign(att):
     return st
 
 
+@on_tensor_device
 def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_proposal2=300, return_aux=False):
     """PEM/utils/model_utils.py:204-275.  model (B,P,3) RAW CAD points and radius (B,): the division
     model / (radius + 1e-6) of coarse_point_matching.py:60 happens inside the scoring kernel.
@@ -649,6 +665,7 @@ def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_
     return Rb, tb
 
 
+@on_tensor_device
 def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     """PEM/utils/model_utils.py:343-436: (B,N,3) x2 [+ (B,N)] -> R (B,3,3), t (B,3)."""
     B, N, _ = src.shape
@@ -659,6 +676,7 @@ def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     return R, t
 
 
+@on_tensor_device
 def compute_fine_Rt(att, pts1, pts2, model, radius, dis_thres=0.15):
     """PEM/utils/model_utils.py:308-341 + the translation rescale of fine_point_matching.py:78.
     Returns R (B,3,3), t (B,3) already multiplied by (radius + 1e-6), score (B,)."""
@@ -676,6 +694,7 @@ def compute_fine_Rt(att, pts1, pts2, model, radius, dis_thres=0.15):
     return R, t, score
 
 
+@on_tensor_device
 def fine_match(f, B, n, temp, pts2):
     """f (2B*n, 256) out_proj outputs [scene clouds; template clouds] -> label1, label2 (B,n-1) i32, pred (B,n-1,3), weight (B,n-1)
     (compute_feature_similarity + the soft-assignment head of compute_fine_Rt, PEM/utils/model_utils.py:131-153, 308-331)."""
@@ -809,6 +828,7 @@ DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0
                    pe_radius1=0.1, pe_radius2=0.2, pe_nsample1=32, pe_nsample2=64, dis_thres=0.15)
 
 
+@on_tensor_device
 def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False):
     """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
@@ -930,6 +950,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     return R, t, sc
 
 
+@on_tensor_device
 def radius_normalize(pts, dense_po):
     """ViTEncoder.forward's radius normalisation (PEM/model/feature_extraction.py:133-137):
     -> dense_pm (B,M,3), dense_po (B,N,3) both divided by (radius + 1e-6), radius (B,)."""
@@ -947,6 +968,7 @@ def radius_normalize(pts, dense_po):
     return pm, po, radius
 
 
+@on_tensor_device
 def depth_to_cloud(depth, K, bbox=None):
     """get_point_cloud_from_depth (PEM/utils/data_utils.py:92-110) on a device depth map (H,W) f32 -> (h,w,3)."""
     from .ops import _chk
@@ -960,6 +982,7 @@ def depth_to_cloud(depth, K, bbox=None):
     return out
 
 
+@on_tensor_device
 def proposal_geometry(masks, depth, K, radius, cap=None):
     """The per-proposal geometry of get_test_data before the random choice (PEM/run_inference_custom_pytorch.py:316-337):
     masks (N,H,W) uint8/bool, depth (H,W) f32 metres, K 3x3, radius = max CAD point norm.

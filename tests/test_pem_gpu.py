@@ -457,6 +457,29 @@ def test_procrustes_golden(dev):
     _close(tw, g["tw"], 2e-5, "weighted procrustes t")
 
 
+@pytest.mark.parametrize("sa,sw", [(1.0e6, 1.0), (1.0, 3.0e5), (1.0e-6, 1.0), (1.0e-6, 1.0e-5), (2.0e5, 1.0e-7), (1.0e15, 1.0e-12)])
+def test_gemm_operand_range(dev, sa, sw):
+    """sam6d_gemm_nt in the default split-precision mode must hold its ~1e-6 relative bound whatever the operands' magnitude: without
+    the per-tile power-of-two scaling |x| >= 65520 turned into inf / NaN and uniformly small operands (1e-6) lost their fp16 lo halves
+    (and most of their hi halves) to subnormals."""
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("split-precision mode only")
+    g = torch.Generator().manual_seed(int(abs(math.log10(sa)) * 10 + abs(math.log10(sw))))
+    M, N, K = 700, 256, 256
+    A = torch.randn(M, K, generator=g) * sa
+    A[:, ::7] *= 1e-3  # mixed magnitudes inside a tile
+    Wt = torch.randn(N, K, generator=g) * sw
+    want = A.double() @ Wt.double().t()
+    out = torch.empty(M, N, device=dev)
+    pem.gemm(A.to(dev), Wt.to(dev), None, out, M, N, K, K, K, N)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err < 4e-6 * scale, "relative error %.2e of the result scale" % (err / scale)
+
+
 # --------------------------------------------------------------------------------------------------- end to end
 def _to(dev, inp):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}

@@ -201,3 +201,23 @@ def test_ball_query2_equals_two_single_queries(dev, B, N, M, r1, ns1, r2, ns2):
               i2.data_ptr(), None)
     torch.cuda.synchronize()
     assert torch.equal(i1, single[0]) and torch.equal(i2, single[1])
+
+
+def test_fps_grid_barrier_abort_falls_back(dev):
+    """The multi-workgroup FPS (N > 4096) closes every round with a hand-rolled grid-wide barrier that needs all its workgroups on the
+    chip.  When a workgroup gives up waiting (forced here: spin cap 0) the cloud is recomputed by the one-workgroup kernel queued behind
+    it -- the call must still return the exact indices, never a truncated list."""
+    from oracle import pointops as P
+    from sam6d_hip import _lib, ops
+    g = torch.Generator().manual_seed(41)
+    xyz = torch.rand(2, 9000, 3, generator=g) - 0.5
+    want = P.furthest_point_sampling(xyz, 300)
+    try:
+        _lib.call("sam6d_fps_debug_spin_cap", 0)
+        got = ops.furthest_point_sampling(xyz.to(dev), 300)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call("sam6d_fps_debug_spin_cap", -1)
+    assert torch.equal(got.cpu(), want.to(torch.int32)), "indices after a forced abort of the grid kernel"
+    again = ops.furthest_point_sampling(xyz.to(dev), 300)  # default cap: the grid kernel completes
+    assert torch.equal(again.cpu(), want.to(torch.int32))
