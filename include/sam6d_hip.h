@@ -213,6 +213,9 @@ int sam6d_prepend_bg_point(const float* pts, int B, int n, float* out, void* str
 /* y = x + s (new_xyz = pts + 1e-8, PEM/model/fine_point_matching.py:117) and a flat device copy of n floats
  * (batch stacking: the .repeat / torch.cat call sites PEM/run_inference_custom_pytorch.py:445-446). */
 int sam6d_add_scalar(const float* x, float s, long n, float* y, void* stream);
+/* flag[0] = 1 if x (B, n) holds B bitwise-identical rows, else 0: recognises the template tensors the reference's caller
+ * `.repeat`s per instance (PEM/run_inference_custom_pytorch.py:445-446), whose pose-independent work then runs once. */
+int sam6d_batch_rows_equal(const float* x, int B, long n, int* flag, void* stream);
 int sam6d_copy_f32(const float* src, float* dst, long n, void* stream);
 /* F.normalize(dim=-1) on 256-wide rows (PEM/utils/model_utils.py:141-142). */
 int sam6d_l2norm256(const float* x, float* y, long rows, long ldx, long ldy, void* stream);

@@ -405,6 +405,28 @@ extern "C" int sam6d_put_rows(const float* src, long s_src_b, long ld_src, float
   SAM6D_LAUNCH_CHECK("put_rows");
 }
 
+// flag[0] &= (x[b] == x[0] bitwise for every b): detects the `.repeat`ed template tensors of the reference's caller
+// (PEM/run_inference_custom_pytorch.py:445-446) so that their pose-independent work can run once.  flag is preset to 1 here.
+__global__ __launch_bounds__(256) void batch_rows_equal_kernel(const unsigned* __restrict__ x, int B, long n, int* __restrict__ flag) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned v = x[i];
+  bool same = true;
+  for (int b = 1; b < B; ++b) same = same && (x[(size_t)b * n + i] == v);
+  if (!same) atomicAnd(flag, 0);
+}
+__global__ void set_flag_kernel(int* p, int v) { *p = v; }
+
+extern "C" int sam6d_batch_rows_equal(const float* x, int B, long n, int* flag, void* stream) {
+  SAM6D_REQUIRE(x && flag && B >= 0 && n >= 0, "batch_rows_equal: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, s, flag, 1);
+  if (B > 1 && n > 0)
+    hipLaunchKernelGGL(batch_rows_equal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const unsigned*>(x), B,
+                       n, flag);
+  SAM6D_LAUNCH_CHECK("batch_rows_equal");
+}
+
 // cat([bg_point(100,100,100), sparse points]) for the geometric embedding (PEM/model/pose_estimation_model.py:30-34)
 __global__ void prepend_bg_point_kernel(const float* __restrict__ p, int n, long total, float* __restrict__ o) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;  // over B*(n+1)

@@ -32,6 +32,8 @@ class Net(nn.Module):
     # attention without the (B,197,197,256) embedding tensors).  False: module by module through the reference's own call
     # graph below (geo embeddings materialised and handed from module to module), same results to ~1e-6.
     fused = True
+    # None: detect per call whether all proposals share one template cloud; True / False: the caller's promise
+    shared_template = None
 
     def _whole_weights(self):
         sig = _sig(self)
@@ -56,8 +58,12 @@ class Net(nn.Module):
             cfg = _cfg_dict(self.coarse_point_matching.cfg, _cfg_dict(self.fine_point_matching.cfg))
             cfg.update(coarse_npoint=self.coarse_npoint, sigma_d=self.geo_embedding.sigma_d, sigma_a=self.geo_embedding.sigma_a,
                        angle_k=self.geo_embedding.angle_k)
+            # the reference's caller repeats one object's template tensors per instance (run_inference_custom_pytorch.py:445-446):
+            # recognised here (bitwise comparison on the device), their pose-independent work then runs once
+            shared = _pem.template_is_shared(dense_po, dense_fo) if self.shared_template is None else bool(self.shared_template)
             return _pem.pem_match(dense_pm.contiguous(), dense_fm.contiguous(), dense_po.contiguous(), dense_fo.contiguous(),
-                                  radius.reshape(-1).contiguous(), model.contiguous(), W, rand.contiguous(), cfg=cfg)
+                                  radius.reshape(-1).contiguous(), model.contiguous(), W, rand.contiguous(), cfg=cfg,
+                                  shared_template=shared)
         bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device) * 100
         sparse_pm, sparse_fm, fps_idx_m = sample_pts_feats(dense_pm, dense_fm, self.coarse_npoint, return_index=True)
         geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm], dim=1))

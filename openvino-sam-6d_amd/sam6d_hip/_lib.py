@@ -48,6 +48,7 @@ SIGNATURES = {
     "sam6d_prepend_bg_point": [c_p, c_i, c_i, c_p, c_p],
     "sam6d_add_scalar": [c_p, c_f, c_l, c_p, c_p],
     "sam6d_copy_f32": [c_p, c_p, c_l, c_p],
+    "sam6d_batch_rows_equal": [c_p, c_i, c_l, c_p, c_p],
     "sam6d_l2norm256": [c_p, c_p, c_l, c_l, c_l, c_p],
     "sam6d_soft_assign": [c_p, c_i, c_i, c_i] + [c_p] * 7 + [c_l, c_p],
     "sam6d_coarse_weights": [c_p, c_i, c_i, c_i] + [c_p] * 9,

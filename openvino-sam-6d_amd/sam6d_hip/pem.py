@@ -763,38 +763,52 @@ def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=Fal
     return out
 
 
-def fine_static_a(dp, df, W, cfg):
+def fine_static_a(dp, df, W, cfg, shared_template=False):
     """First half of fine_static: token buffer D with in_proj of both clouds + the template cloud's ball queries (ordinary
-    grids that share the chip well)."""
-    B = dp.shape[0] // 2
+    grids that share the chip well).  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
+    dense_fo `.repeat`ed per instance, PEM/run_inference_custom_pytorch.py:445-446): its tokens are computed once, in slot B."""
+    Bp, N, K = df.shape
+    B = Bp // 2
+    if shared_template and B > 1:
+        lin = W.fine["in_proj"]
+        D = _empty((Bp, N + 1, C), df)
+        gemm(df, lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B + 1, sA=N * K, sC=(N + 1) * C)  # scene clouds + template slot B
+        _lib.call("sam6d_put_rows", _p(W.fine["bg"]), 0, C, _p(D), (N + 1) * C, C, B + 1, 1, C, _s())
+        grp = pe_group(dp[B:B + 1], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
+        return D, grp
     D = _tokens_with_bg(df, W.fine["in_proj"], W.fine["bg"])
     grp = pe_group(dp[B:], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
     return D, grp
 
 
-def fine_static_b(dp, D, grp, W):
-    """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run)."""
+def fine_static_b(dp, D, grp, W, shared_template=False):
+    """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run).
+    shared_template: one cloud's worth, then the finished token block of slot B is copied to the other template slots."""
     Bp, N, _ = dp.shape
     B = Bp // 2
+    if shared_template and B > 1:
+        pe_apply(dp[B:B + 1], grp, W, D, B * (N + 1) * C + C, (N + 1) * C)
+        _lib.call("sam6d_put_rows", _p(D, B * (N + 1) * C), 0, C, _p(D, (B + 1) * (N + 1) * C), (N + 1) * C, C, B - 1, N + 1, C, _s())
+        return D
     pe_apply(dp[B:], grp, W, D, B * (N + 1) * C + C, (N + 1) * C)
     return D
 
 
-def fine_static(dp, df, W, cfg):
+def fine_static(dp, df, W, cfg, shared_template=False):
     """The part of FinePointMatching.forward that does not depend on the coarse pose: in_proj of both clouds' dense
     features into the token buffer D (2B,N+1,256) with the bg token, and the positional encoding of the TEMPLATE cloud
     (PEM/model/fine_point_matching.py:47-51).  pem_match issues it on a side stream, under the latency-bound coarse stage."""
-    D, grp = fine_static_a(dp, df, W, cfg)
-    return fine_static_b(dp, D, grp, W)
+    D, grp = fine_static_a(dp, df, W, cfg, shared_template)
+    return fine_static_b(dp, D, grp, W, shared_template)
 
 
-def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None):
+def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None, shared_template=False):
     """dp (2B,N,3), df (2B,N,256) stacked [scene; template]  (PEM/model/fine_point_matching.py:42-79, eval).
     D: the result of fine_static() when the caller has already produced it."""
     Bp, N, _ = dp.shape
     B = Bp // 2
     if D is None:
-        D = fine_static(dp, df, W, cfg)
+        D = fine_static(dp, df, W, cfg, shared_template)
     p1 = _empty((B, N, 3), dp)
     _lib.call("sam6d_rigid_inverse", _p(dp), _p(init_R), _p(init_t), B, N, _p(p1), _s())  # p1_ = (p1 - t) @ R
     positional_encoding_add(p1, W, D, C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"],
@@ -829,10 +843,15 @@ DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0
 
 
 @on_tensor_device
-def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False):
+def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False,
+              shared_template=False):
     """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
+    shared_template=True: the caller guarantees dense_po[b] == dense_po[0] and dense_fo[b] == dense_fo[0] for every proposal (the
+    reference's caller repeats one object's template tensors per instance, run_inference_custom_pytorch.py:445-446): the template
+    side of the pose-independent fine work (in_proj of 2048 dense tokens, both ball queries, both PE MLPs, mlp3) then runs once
+    instead of B times; the result is bit-identical to the repeated form.
 
     cfg["microbatch"] = k (env SAM6D_MICROBATCH, default 1 = off): the batch is cut into k slices whose coarse / fine stages run
     on k HIP streams (one slice's latency-bound chains beside another's dense kernels, +2 % at k = 2, twice the host launch work).
@@ -853,7 +872,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         side = _side_stream(dp.device, side_key)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            D = fine_static(dp, df, W, cfg)
+            D = fine_static(dp, df, W, cfg, shared_template)
         D.record_stream(cur)
         return D, side
 
@@ -872,7 +891,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
             side = _side_stream(dp.device, side_key)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                D, grp = fine_static_a(dp, df, W, cfg)
+                D, grp = fine_static_a(dp, df, W, cfg, shared_template)
         n = cfg["coarse_npoint"]
         sp, sf, idx = sample_pts_feats(dp, df, n)
         pb = _empty((2 * b, n + 1, 3), dp)
@@ -905,14 +924,14 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
                 ev.record(cur)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    fine_static_b(dp, D, grp, W)
+                    fine_static_b(dp, D, grp, W, shared_template)
         elif overlap:
             D, side = fork_fine_static(dp, df, side_key)
         c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux, before_pose=hook)
         R0, t0 = c[0], c[1]
         if D is not None:
             torch.cuda.current_stream().wait_stream(side)
-        f = fine_point_matching(dp, df, E, idx, rad, mod, R0, t0, W, cfg, return_aux, D=D)
+        f = fine_point_matching(dp, df, E, idx, rad, mod, R0, t0, W, cfg, return_aux, D=D, shared_template=shared_template)
         if return_aux:
             b = hi - lo
             return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:b], fps_idx_o=idx[b:],
@@ -948,6 +967,19 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
             src.record_stream(main)
             _lib.call("sam6d_copy_f32", _p(src), _p(dst, lo * w), src.numel(), _s())
     return R, t, sc
+
+
+def template_is_shared(dense_po, dense_fo):
+    """True when every proposal carries the same template cloud (bitwise), i.e. the caller `.repeat`ed one object's tensors
+    (PEM/run_inference_custom_pytorch.py:445-446).  One host read-back."""
+    B = dense_po.shape[0]
+    if B < 2:
+        return False
+    flags = torch.empty(2, dtype=torch.int32, device=dense_po.device)
+    _lib.call("sam6d_batch_rows_equal", _p(dense_po.contiguous()), B, dense_po[0].numel(), flags.data_ptr(), _s())
+    _lib.call("sam6d_batch_rows_equal", _p(dense_fo.contiguous()), B, dense_fo[0].numel(), flags.data_ptr() + 4, _s())
+    f = flags.cpu()
+    return bool(f[0]) and bool(f[1])
 
 
 @on_tensor_device

@@ -195,3 +195,26 @@ def test_fine_stage_labels_and_weights_vs_oracle(dev, which):
               wgt.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _close(wgt, want_w, 1e-5, "assignment weights")
     _close(pred, want_pred, 1e-5, "weighted targets")
+
+
+# ------------------------------------------------------------------------------------------- template-side de-duplication (8e)
+def test_shared_template_equals_repeated_form(dev, W):
+    """One object, 12 proposals: dense_po / dense_fo are one cloud `.repeat`ed per instance (PEM/run_inference_custom_pytorch.py:445-446).
+    pem_match(shared_template=True) computes the template's dense tokens (in_proj, ball queries, PE MLPs) once and must return bit for
+    bit what the repeated form returns; the detector recognises the repetition and rejects a single differing element."""
+    from sam6d_hip import pem, synth
+    B = 12
+    inp = synth.config2_inputs(B=B, seed=9)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    d["dense_po"] = d["dense_po"][:1].repeat(B, 1, 1).contiguous()
+    d["dense_fo"] = d["dense_fo"][:1].repeat(B, 1, 1).contiguous()
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    assert pem.template_is_shared(d["dense_po"], d["dense_fo"])
+    a = pem.pem_match(*[d[k] for k in keys], W, d["rand"])
+    b = pem.pem_match(*[d[k] for k in keys], W, d["rand"], shared_template=True)
+    for x, y, what in zip(a, b, ("R", "t", "score")):
+        assert torch.equal(x, y), "%s differs between the repeated and the shared-template form: %.3e" % (what, float((x - y).abs().max()))
+    other = d["dense_fo"].clone()
+    other[B - 1, 2047, 255] += 1.0
+    assert not pem.template_is_shared(d["dense_po"], other)
+    assert not pem.template_is_shared(d["dense_po"][:1], d["dense_fo"][:1])
