@@ -331,7 +331,7 @@ struct TbSched {
 };
 
 template <int MODE, int WAVES, int NBUF>
-__global__ __launch_bounds__(WAVES * 64) void token_block_kernel(TbArgs a) {
+__global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) {  // (2 waves per SIMD: <= 256 VGPR + AGPR)
   constexpr int TB_TOK = 16 * WAVES, TB_NBUF = NBUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* pan = lds;                                                   // TB_NBUF x TB_PANEL_BYTES ring
@@ -429,6 +429,20 @@ __global__ __launch_bounds__(WAVES * 64) void token_block_kernel(TbArgs a) {
     }
   }
 
+  // mode 1: the split input rows D stay in registers for the residual add three products later (re-reading them cost a second
+  // 134 MB pass over D per layer: 1.7x the layer's algorithmic traffic, rocprof FETCH_SIZE)
+  half8 dh[MODE ? 8 : 1], dl[MODE ? 8 : 1];
+  const float sd = sx;
+  if constexpr (MODE != 0) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      dh[s] = xh[s];
+      dl[s] = xl[s];
+      tb_opaque(dh[s]);
+      tb_opaque(dl[s]);
+    }
+  }
+
   f32x4 acc[16];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -506,10 +520,19 @@ __global__ __launch_bounds__(WAVES * 64) void token_block_kernel(TbArgs a) {
   });
   {
     const float inv = cst[TC_SC + 1] * (1.0f / sx);
-    const float* rs = (MODE ? a.in : a.resid) + (size_t)row * 256;
+    const float* rs = a.resid + (size_t)row * 256;
+    const float isd = 1.0f / sd;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float4 rv = *reinterpret_cast<const float4*>(rs + 16 * i + 4 * fg);
+      float4 rv;
+      if constexpr (MODE != 0) {  // D = (hi + lo) / scale: 22 significand bits of the fp32 input
+        rv.x = ((float)dh[i >> 1][4 * (i & 1) + 0] + (float)dl[i >> 1][4 * (i & 1) + 0]) * isd;
+        rv.y = ((float)dh[i >> 1][4 * (i & 1) + 1] + (float)dl[i >> 1][4 * (i & 1) + 1]) * isd;
+        rv.z = ((float)dh[i >> 1][4 * (i & 1) + 2] + (float)dl[i >> 1][4 * (i & 1) + 2]) * isd;
+        rv.w = ((float)dh[i >> 1][4 * (i & 1) + 3] + (float)dl[i >> 1][4 * (i & 1) + 3]) * isd;
+      } else {
+        rv = *reinterpret_cast<const float4*>(rs + 16 * i + 4 * fg);
+      }
       const float4 bl = *reinterpret_cast<const float4*>(cst + TC_BLIN + 16 * i + 4 * fg);
       acc[i][0] = (acc[i][0] * inv + bl.x) + rv.x;
       acc[i][1] = (acc[i][1] * inv + bl.y) + rv.y;
