@@ -181,6 +181,14 @@ int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const int* list_ws,
 int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n, int ncol, float* dst, long ld_dst,
                     long stride_dst, void* stream);
 
+/* Cross attention of a TransformerLayer with the query projection inside (PEM/model/transformer.py:95-150: proj_q, per-head
+ * softmax(q k^T / 8) v for 4 heads x 64) on the matrix cores, one workgroup per (cloud, head).  x (B,n,256) query-side tokens;
+ * kv (B,m,512) = [proj_k | proj_v] of the memory tokens (one sam6d_gemm_nt); wq_image = sam6d_pack_panels(proj_q.weight, 256 rows,
+ * k0 = 0, ksteps = 8, scale s) (256 KiB), inv_wq_scale = 1 / s; bq (256).  out (B,n,256) = the attention output before
+ * AttentionLayer.linear.  n <= 256, m <= 208. */
+int sam6d_cross_attention(const float* x, const float* kv, const void* wq_image, const float* bq, float inv_wq_scale, float* out,
+                          int B, int n, int m, void* stream);
+
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).
  * RPE form: qp (B,n,4,256) = per-head query folded through proj_p, E (B,n,m,256); pass both NULL for the plain form. */

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void tb_pack_kernel(const float* __restrict__ 
     const int m = i / (KS * 32), p = i % (KS * 32);
     const int col = k0 + 32 * (p >> 5) + tb_slot_channel(p & 31);
     const float v = W[(size_t)(panel * 32 + m) * ldw + col] * scale;
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16 hi, lo;
+    sam6d_split_f16(v, hi, lo);
     // logical half index -> 16-byte chunk (8 halves) -> swizzled chunk
     const int ch = p >> 3, cl = (KS * 32 + p) >> 3;
     _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)m * rowb);
@@ -126,11 +126,12 @@ __global__ __launch_bounds__(256) void tb_kv_pack_kernel(const float* __restrict
     const int hd = i >> 12, d = (i >> 6) & 63, p = i & 63;  // p: slot inside the 64-wide K
     const int c = 32 * (p >> 5) + tb_slot_channel(p & 31);
     const float v = src[(hd * 64 + d) * 64 + c] * scale;
-    const _Float16 hi = (_Float16)v;
+    _Float16 hi, lo;
+    sam6d_split_f16(v, hi, lo);
     const int m = d & 31;
     _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)(2 * hd + (d >> 5)) * TB_P64 + (size_t)m * TB_ROWB(2));
     row[(((p >> 3) ^ (m & 15)) << 3) + (p & 7)] = hi;
-    row[((((64 + p) >> 3) ^ (m & 15)) << 3) + (p & 7)] = (_Float16)(v - (float)hi);
+    row[((((64 + p) >> 3) ^ (m & 15)) << 3) + (p & 7)] = lo;
   }
 }
 
@@ -244,10 +245,10 @@ __device__ __forceinline__ float tb_split_rows(const f32x4* v, half8* xh, half8*
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float x = v[t][r] * sc;
-      const _Float16 hi = (_Float16)x;
+      _Float16 hi, lo;
+      sam6d_split_f16(v[t][r] * sc, hi, lo);
       xh[t >> 1][4 * (t & 1) + r] = hi;
-      xl[t >> 1][4 * (t & 1) + r] = (_Float16)(x - (float)hi);
+      xl[t >> 1][4 * (t & 1) + r] = lo;
     }
   return sc;
 }
@@ -421,10 +422,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
       const float e[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb[s].x, vb[s].y, vb[s].z, vb[s].w};
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float x = e[u] * sx;
-        const _Float16 hi = (_Float16)x;
+        _Float16 hi, lo;
+        sam6d_split_f16(e[u] * sx, hi, lo);
         xh[s][u] = hi;
-        xl[s][u] = (_Float16)(x - (float)hi);
+        xl[s][u] = lo;
       }
     }
   }
@@ -569,9 +570,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
           for (int r = 0; r < 4; ++r) {
             float v = ha[w][r] * inv_e + bb[r];
             v = (v > 0.f ? v : 0.f) * sh;
-            const _Float16 hi = (_Float16)v;
+            _Float16 hi, lo;
+            sam6d_split_f16(v, hi, lo);
             hh[u][4 * w + r] = hi;
-            hl[u][4 * w + r] = (_Float16)(v - (float)hi);
+            hl[u][4 * w + r] = lo;
           }
         }
       });

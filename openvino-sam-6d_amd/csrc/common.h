@@ -159,6 +159,16 @@ __device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// fp32 -> fp16 (hi, lo) pair with hi + lo = x to 22 significand bits.  x is first made opaque to the optimiser: when x is the product
+// of a multiplication, clang folds the multiplication into ONE of the conversions (v_fma_mixlo_f16: a single rounding of the exact
+// product) and uses the separately rounded fp32 product for the other; on a rounding tie the two disagree and hi + lo is off by one
+// fp16 ulp of hi (found as a 3e-5 error of a single softmax probability, 2^-11 relative).  The empty asm costs no instruction.
+__device__ __forceinline__ void sam6d_split_f16(float x, _Float16& hi, _Float16& lo) {
+  asm("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // One-time per-DEVICE setup (hipFuncSetAttribute, CU count ...): `done` is a bit mask over device ordinals owned by the call site;

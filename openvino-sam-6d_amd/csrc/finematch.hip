@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void fm_prep_kernel(const float* __restrict__ 
   half4 hi, lo;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    hi[u] = (_Float16)x[u];
-    lo[u] = (_Float16)(x[u] - (float)hi[u]);
+    _Float16 h, l;
+    sam6d_split_f16(x[u], h, l);
+    hi[u] = h;
+    lo[u] = l;
   }
   *reinterpret_cast<half4*>(fh + row * FM_C + lane * 4) = hi;
   *reinterpret_cast<half4*>(fl + row * FM_C + lane * 4) = lo;

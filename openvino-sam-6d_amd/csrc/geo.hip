@@ -284,11 +284,13 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   auto produce1 = [&](int kc, int u) {  // one sin/cos pair of chunk kc's sinusoid row, split into fp16 hi/lo
     float sv, cv;
     fast_sincosf(xrow * om[kc * 8 + gf0 + u], &sv, &cv);
-    const _Float16 sh = (_Float16)sv, ch = (_Float16)cv;
+    _Float16 sh, sl, ch, cl;
+    sam6d_split_f16(sv, sh, sl);
+    sam6d_split_f16(cv, ch, cl);
     ahi[2 * u] = sh;
     ahi[2 * u + 1] = ch;
-    alo[2 * u] = (_Float16)(sv - (float)sh);
-    alo[2 * u + 1] = (_Float16)(cv - (float)ch);
+    alo[2 * u] = sl;
+    alo[2 * u + 1] = cl;
   };
 #pragma unroll
   for (int u = 0; u < 4; ++u) produce1(0, u);
@@ -345,10 +347,10 @@ __global__ void split_f16_kernel(const float* __restrict__ x, long n, float scal
                                  _Float16* __restrict__ lo) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
-  const float v = x[e] * scale;
-  const _Float16 h = (_Float16)v;
+  _Float16 h, l;
+  sam6d_split_f16(x[e] * scale, h, l);
   hi[e] = h;
-  lo[e] = (_Float16)(v - (float)h);
+  lo[e] = l;
 }
 
 extern "C" int sam6d_split_f16(const float* x, long n, float scale, void* hi, void* lo, void* stream) {

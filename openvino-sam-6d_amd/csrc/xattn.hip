@@ -1,0 +1,293 @@
+// Cross attention of the sparse (197-token) transformer layers on the matrix cores, with the query projection inside
+// (TransformerLayer / AttentionLayer / MultiHeadAttention of PEM/model/transformer.py:95-150):
+//     q = x Wq^T + bq;   per head h:  P = softmax(q_h k_h^T / sqrt(64));   hidden[:, 64h .. 64h+64) = P v_h
+// k and v come from the key-side projection (one GEMM over the memory tokens, unchanged).
+//
+// Before: proj_q GEMM (20 us) + a VALU attention kernel that walks the 197 keys of every query with wave butterflies (67 us), twelve
+// times per step.  Here one workgroup owns a (cloud, head): the 197 x 64 keys and values of that head are cut into fp16 hi / lo halves
+// ONCE into LDS images, and every 16-query group runs three register-chained, transposed products on v_mfma_f32_16x16x32_f16 (same
+// scheme as block.hip: a lane holds channels of its own token, the accumulator of one product is the B operand of the next):
+//     q^T (64 x tok)  = Wq_h (64 x 256)  . x^T          8 k-steps
+//     S^T (keys x tok) = k_h (208 x 64)  . q^T          2 k-steps, 13 key tiles; softmax over the lane's 52 values + 3 partner lanes
+//     out^T (64 x tok) = v_h^T (64 x 224) . P^T         7 k-steps
+// fp16 x3 split products with power-of-two operand scales (per token row for x, q, P; per image for Wq, k, v): range-safe, ~1e-6.
+#include "common.h"
+#include "../../include/sam6d_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define XA_MAXKEY 208     // 13 key tiles of 16
+#define XA_NT 13
+#define XA_WAVES 8
+#define XA_WQ_BYTES 65536            // Wq_h image: 64 rows x 1 KiB (K = 256: hi | lo), also the v^T image (K = 224 keys + pad)
+#define XA_K_BYTES (XA_MAXKEY * 256) // k_h image: 208 rows x 256 B (K = 64: hi | lo)
+#define XA_LDS (XA_WQ_BYTES + XA_K_BYTES + 64)
+
+// slot p (0..31) of a 32-wide k-step <-> channel (see block.hip): channel = 16 (e >> 2) + 4 g + (e & 3), p = 8 g + e
+__device__ __forceinline__ int xa_channel_slot(int c) { return 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3); }
+
+__device__ __forceinline__ float xa_pow2_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);
+  e = 14 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+__device__ __forceinline__ float xa_tok_max(float m) {
+  m = fmaxf(m, xor16_f32(m));
+  return fmaxf(m, xor32_f32(m));
+}
+__device__ __forceinline__ float xa_tok_sum(float s) {
+  s += xor16_f32(s);
+  return s + xor32_f32(s);
+}
+
+// acc (16 out rows x 16 tokens) += W[rows r0 .. r0+16) . X over KS k-steps.  Image rows are ROWB bytes: hi plane then lo plane (LOCH
+// 16-byte chunks further), chunk c stored at (c & ~15) | ((c ^ row) & 15).
+template <int ROWB, int LOCH, int KS>
+__device__ __forceinline__ void xa_mma(f32x4& acc, const unsigned char* __restrict__ img, int r0, const half8* __restrict__ xh,
+                                       const half8* __restrict__ xl, int fr, int fg) {
+  const int row = r0 + fr;
+  const unsigned char* rb = img + (size_t)row * ROWB;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int ch = 4 * s + fg, cl = LOCH + 4 * s + fg;
+    const half8 ah = *reinterpret_cast<const half8*>(rb + (((ch & ~15) | ((ch ^ row) & 15)) << 4));
+    const half8 al = *reinterpret_cast<const half8*>(rb + (((cl & ~15) | ((cl ^ row) & 15)) << 4));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[s], acc, 0, 0, 0);
+  }
+}
+
+struct XaArgs {
+  const float* x;     // (B, n, 256) query-side tokens
+  const float* kv;    // (B, m, 512): k | v of the memory tokens
+  const unsigned char* wq;  // 4 heads x 64 KiB: proj_q rows 64h .. 64h+64 as two swizzled K = 256 panels (sam6d_pack_panels)
+  const float* bq;    // (256)
+  float* out;         // (B, n, 256)
+  int n, m;
+  float inv_wq;       // 1 / pack scale of Wq
+};
+
+__global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* regA = lds;                    // Wq_h image, later the v_h^T image
+  unsigned char* kimg = lds + XA_WQ_BYTES;      // k_h image
+  float* red = reinterpret_cast<float*>(lds + XA_WQ_BYTES + XA_K_BYTES);  // 16 floats
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = a.n, m = a.m;
+
+  // ---- Wq_h image by LDS-DMA (64 pieces of 1 KiB), k_h image built here from the fp32 keys
+  {
+    const unsigned char* src = a.wq + (size_t)h * XA_WQ_BYTES;
+#pragma unroll
+    for (int k = 0; k < 64 / XA_WAVES; ++k) {
+      const int pc = wave + XA_WAVES * k;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                       (void __attribute__((address_space(3)))*)(regA + pc * 1024), 16, 0, 0);
+    }
+  }
+  const float* kb = a.kv + (size_t)b * m * 512 + 64 * h;
+  const float* vb = kb + 256;
+  float mk = 0.f, mv = 0.f;
+  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
+    const int j = e >> 6, d = e & 63;
+    mk = fmaxf(mk, fabsf(kb[(size_t)j * 512 + d]));
+    mv = fmaxf(mv, fabsf(vb[(size_t)j * 512 + d]));
+  }
+  mk = wave_max_dpp(mk);
+  mv = wave_max_dpp(mv);
+  if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
+  for (int i = t; i < XA_K_BYTES / 4; i += XA_WAVES * 64) reinterpret_cast<unsigned*>(kimg)[i] = 0u;
+  __syncthreads();
+  float sk = 0.f, sv = 0.f;
+#pragma unroll
+  for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
+  sk = xa_pow2_scale(sk);
+  sv = xa_pow2_scale(sv);
+  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
+    const int j = e >> 6, d = e & 63;
+    const float v = kb[(size_t)j * 512 + d] * sk;
+    _Float16 hi, lo;
+    sam6d_split_f16(v, hi, lo);
+    const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);  // half index in the hi plane (K = 64)
+    _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
+    const int ch = p >> 3, cl = 8 + (p >> 3);
+    row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
+    row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
+  }
+
+  // ---- phase 1: q^T for this wave's token groups (kept as split B fragments: 2 k-steps each)
+  const int ngroups = (n + 15) >> 4;
+  half8 qh[2][2], ql[2][2];
+  float sq[2] = {1.f, 1.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // Wq image landed, k image complete
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int grp = wave + XA_WAVES * gi;
+    if (grp < ngroups) {  // (wave-uniform)
+      const int tok = min(grp * 16 + fr, n - 1);
+      const float* src = a.x + ((size_t)b * n + tok) * 256;
+      half8 xh[8], xl[8];
+      {
+        float4 va[8], vb4[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
+          vb4[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[s].x), fabsf(va[s].y)), fmaxf(fabsf(va[s].z), fabsf(va[s].w))));
+          mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb4[s].x), fabsf(vb4[s].y)), fmaxf(fabsf(vb4[s].z), fabsf(vb4[s].w))));
+        }
+        const float sx = xa_pow2_scale(xa_tok_max(mx));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const float e8[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb4[s].x, vb4[s].y, vb4[s].z, vb4[s].w};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            _Float16 hi, lo;
+            sam6d_split_f16(e8[u] * sx, hi, lo);
+            xh[s][u] = hi;
+            xl[s][u] = lo;
+          }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          xa_mma<1024, 32, 8>(acc[i], regA, 16 * i, xh, xl, fr, fg);
+        }
+        // q = acc / (s_wq sx) + bq, times 1/8 (the softmax scale 1/sqrt(64): a power of two, folded here)
+        const float inv = a.inv_wq * (1.0f / sx) * 0.125f;
+        float qm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.bq + 64 * h + 16 * i + 4 * fg);
+          acc[i][0] = acc[i][0] * inv + bb.x * 0.125f;
+          acc[i][1] = acc[i][1] * inv + bb.y * 0.125f;
+          acc[i][2] = acc[i][2] * inv + bb.z * 0.125f;
+          acc[i][3] = acc[i][3] * inv + bb.w * 0.125f;
+          qm = fmaxf(qm, fmaxf(fmaxf(fabsf(acc[i][0]), fabsf(acc[i][1])), fmaxf(fabsf(acc[i][2]), fabsf(acc[i][3]))));
+        }
+        sq[gi] = xa_pow2_scale(xa_tok_max(qm));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            _Float16 hi, lo;
+            sam6d_split_f16(acc[i][r] * sq[gi], hi, lo);
+            qh[gi][i >> 1][4 * (i & 1) + r] = hi;
+            ql[gi][i >> 1][4 * (i & 1) + r] = lo;
+          }
+      }
+    }
+  }
+  __syncthreads();  // every wave is done with the Wq image
+
+  // ---- v_h^T image over the Wq region: row d, K = key (7 k-steps of 32, padded to 8), hi plane | lo plane (32 chunks further)
+  for (int i = t; i < XA_WQ_BYTES / 4; i += XA_WAVES * 64) reinterpret_cast<unsigned*>(regA)[i] = 0u;
+  __syncthreads();
+  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
+    const int j = e >> 6, d = e & 63;
+    const float v = vb[(size_t)j * 512 + d] * sv;
+    _Float16 hi, lo;
+    sam6d_split_f16(v, hi, lo);
+    const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
+    _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
+    const int ch = p >> 3, cl = 32 + (p >> 3);
+    row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
+    row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+  }
+  __syncthreads();
+
+  // ---- phases 2 and 3 per token group
+  const float inv_k = 1.0f / sk, inv_v = (1.0f / sv) * (1.0f / 16384.0f);
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int grp = wave + XA_WAVES * gi;
+    if (grp < ngroups) {
+      f32x4 s[XA_NT];
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i) {
+        s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xa_mma<256, 8, 2>(s[i], kimg, 16 * i, qh[gi], ql[gi], fr, fg);
+      }
+      // logits (already / 8), keys >= m masked; softmax over the token's keys
+      const float inv = inv_k * (1.0f / sq[gi]);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * i + 4 * fg + r;
+          s[i][r] = key < m ? s[i][r] * inv : -INFINITY;
+          mx = fmaxf(mx, s[i][r]);
+        }
+      mx = xa_tok_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[i][r] = __builtin_amdgcn_exp2f((s[i][r] - mx) * 1.4426950408889634f);
+          sum += s[i][r];
+        }
+      sum = xa_tok_sum(sum);
+      const float pscale = 16384.0f / sum;  // probabilities times 2^14 (<= 2^14: fp16-safe), the 2^-14 is in inv_v
+      half8 ph[7], pl[7];
+#pragma unroll
+      for (int i = 0; i < 14; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = i < XA_NT ? s[i < XA_NT ? i : 0][r] * pscale : 0.f;
+          _Float16 hi, lo;
+          sam6d_split_f16(pv, hi, lo);
+          ph[i >> 1][4 * (i & 1) + r] = hi;
+          pl[i >> 1][4 * (i & 1) + r] = lo;
+        }
+      f32x4 o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xa_mma<1024, 32, 7>(o[i], regA, 16 * i, ph, pl, fr, fg);
+      }
+      const int tok = grp * 16 + fr;
+      if (tok < n) {
+        float* dst = a.out + ((size_t)b * n + tok) * 256 + 64 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(dst + 16 * i + 4 * fg) = make_float4(o[i][0] * inv_v, o[i][1] * inv_v, o[i][2] * inv_v, o[i][3] * inv_v);
+      }
+    }
+  }
+}
+
+extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void* wq_image, const float* bq, float inv_wq_scale,
+                                     float* out, int B, int n, int m, void* stream) {
+  SAM6D_REQUIRE(x && kv && wq_image && bq && out && B >= 0, "cross_attention: null pointer");
+  SAM6D_REQUIRE(n > 0 && n <= 16 * 2 * XA_WAVES && m > 0 && m <= XA_MAXKEY, "cross_attention: needs n <= %d queries and m <= %d keys per cloud",
+                16 * 2 * XA_WAVES, XA_MAXKEY);
+  SAM6D_REQUIRE(((((size_t)x) | ((size_t)kv) | ((size_t)wq_image) | ((size_t)bq) | ((size_t)out)) & 15) == 0,
+                "cross_attention: pointers must be 16-byte aligned");
+  SAM6D_REQUIRE(B <= 65535 && inv_wq_scale > 0.f, "cross_attention: bad arguments");
+  if (B == 0) return 0;
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)xattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
+    if (e != hipSuccess) {
+      sam6d_set_error("cross_attention: cannot reserve %d bytes of LDS: %s", XA_LDS, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale};
+  hipLaunchKernelGGL(xattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("cross_attention");
+}

@@ -112,6 +112,14 @@ def pack_token_block(L, q=None, scale=None):
     return dict(img=img, cst=cst, mode=mode)
 
 
+def pack_cross_query(q):
+    """proj_q of a cross-attention layer as the panel image of csrc/xattn.hip (head h = rows 64h .. 64h+64 = panels 2h, 2h+1)."""
+    s_q = _pow2_scale(q.w.abs().max())
+    img = torch.zeros(8 * TB_P256, dtype=torch.uint8, device=q.w.device)
+    _lib.call("sam6d_pack_panels", _p(q.w), q.w.shape[1], C, 0, 8, float(s_q), img.data_ptr(), _s())
+    return dict(img=img, inv=1.0 / s_q)
+
+
 class PemWeights:
     """Device-resident weights in the layouts the kernels want, built from a reference-keyed state_dict
     (SURVEY 8b B2).  Packing is pure data movement: concatenating q/k/v projection weights, transposing proj_p, folding
@@ -184,6 +192,7 @@ class PemWeights:
             kv=Linear(torch.cat([g(ca + ".proj_k.weight"), g(ca + ".proj_v.weight")], 0),
                       torch.cat([g(ca + ".proj_k.bias"), g(ca + ".proj_v.bias")], 0)),
             **self._post(g, c))
+        cross_l["xq"] = pack_cross_query(cross_l["q"])
         return dict(self=self_l, cross=cross_l)
 
 
@@ -502,9 +511,15 @@ def cross_layer(x, mem, L):
     B, n, _ = x.shape
     m = mem.shape[1]
     x2 = x.reshape(B * n, C)
-    q = linear(x2, L["q"])
     kv = linear(mem.reshape(B * m, C), L["kv"])  # (B*m, 512): k | v
     hid = _empty((B * n, C), x)
+    if _fused_block() and "xq" in L and n <= 256 and m <= 208:
+        # proj_q + softmax attention of all four heads in one launch on the matrix cores (xattn.hip)
+        with _Timed("cross_attention"):
+            _lib.call("sam6d_cross_attention", _p(x2), _p(kv), L["xq"]["img"].data_ptr(), _p(L["q"].b), float(L["xq"]["inv"]), _p(hid),
+                      B, n, m, _s())
+        return _post_attention(hid, x2, L).reshape(B, n, C)
+    q = linear(x2, L["q"])
     _lib.call("sam6d_attention", _p(q), _p(kv), _p(kv, C), None, None, _p(hid), B, n, m, C, 2 * C, 2 * C, C, n * C, m * 2 * C,
               m * 2 * C, n * C, _s())
     return _post_attention(hid, x2, L).reshape(B, n, C)

@@ -186,3 +186,51 @@ def test_fine_match_equals_unfused_path(dev):
     Ra, ta, sa = pem.compute_fine_Rt(att, pts1, pts2, model, radius)
     Rb, tb, sb = pem.compute_fine_Rt_fused(Fd.reshape(-1, 256).contiguous(), B, n, 0.1, pts1, pts2, model, radius)
     assert float((Ra - Rb).abs().max()) < 1e-5 and float((ta - tb).abs().max()) < 1e-5 and float((sa - sb).abs().max()) < 1e-5
+
+
+# --------------------------------------------------------------------------------------------------- fused cross attention
+@pytest.mark.parametrize("B,n,m,xs", [(2, 197, 197, 1.0), (3, 50, 208, 1.0), (1, 16, 1, 1.0), (2, 64, 32, 1.0), (2, 197, 197, 3.0e4),
+                                      (2, 130, 197, 1.0e-5)])
+def test_cross_attention_vs_fp64(dev, B, n, m, xs):
+    """sam6d_cross_attention (proj_q + 4-head softmax attention, xattn.hip) against a float64 recompute of MultiHeadAttention
+    (PEM/model/transformer.py:95-150); xs scales the query-side tokens and 1 / xs the keys (operands far outside fp16's range, logits
+    of ordinary size: with logits of 1e5 the softmax would be decided by fp32's own last bits).  (2, 64, 32) once had one probability
+    off by 2^-11: clang rounded hi and lo of one fp16 split from differently rounded products (common.h sam6d_split_f16)."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(B * 100 + n + m)
+    mk = lambda o, i: pem.Linear((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i), (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    q = mk(256, 256)
+    x = torch.randn(B, n, 256, generator=gen) * xs
+    kv = torch.randn(B, m, 512, generator=gen)
+    kv[..., :256] /= xs
+    q = pem.Linear(q.w, q.b * xs)
+    d = lambda t: t.double()
+    qq = d(x) @ d(q.w).t() + d(q.b)
+    want = torch.zeros(B, n, 256, dtype=torch.float64)
+    for h in range(4):
+        sl = slice(64 * h, 64 * h + 64)
+        att = torch.softmax(qq[..., sl] @ d(kv[..., sl]).transpose(1, 2) / 8.0, dim=-1)
+        want[..., sl] = att @ d(kv[..., 256:][..., sl])
+    qd = pem.Linear(q.w.to(dev), q.b.to(dev))
+    xq = pem.pack_cross_query(qd)
+    xd, kvd = x.to(dev).contiguous(), kv.to(dev).contiguous()
+    out = torch.full((B, n, 256), float("nan"), device=dev)
+    _lib.call("sam6d_cross_attention", xd.data_ptr(), kvd.data_ptr(), xq["img"].data_ptr(), qd.b.data_ptr(), float(xq["inv"]),
+              out.data_ptr(), B, n, m, torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < 2e-6 * max(1.0, float(want.abs().max())), "cross attention vs fp64: %.3e" % err
+
+
+def test_cross_layer_fused_matches_unfused(dev, monkeypatch):
+    from sam6d_hip import pem, synth
+    W = pem.PemWeights(synth.make_pem_weights(1), dev)
+    L = W.coarse["blocks"][0]["cross"]
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 197, 256, generator=gen).to(dev)
+    mem = torch.randn(5, 197, 256, generator=gen).to(dev)
+    a = pem.cross_layer(x, mem, L)
+    monkeypatch.setenv("SAM6D_FUSED_BLOCK", "0")
+    b = pem.cross_layer(x, mem, L)
+    assert float((a - b).abs().max()) < 3e-5
