@@ -190,8 +190,9 @@ def test_fine_stage_labels_and_weights_vs_oracle(dev, which):
     B, R_, Cn = a.shape
     pred = torch.empty(B, R_ - 1, 3, device=dev)
     wgt = torch.empty(B, R_ - 1, device=dev)
+    p2d = p2.to(dev).contiguous()  # (named: a temporary's memory could be reused before the launch)
     _lib.call("sam6d_fine_assign", a.data_ptr(), B, R_, Cn, st["rmax"].data_ptr(), st["rsum"].data_ptr(), st["cmax"].data_ptr(),
-              st["csum"].data_ptr(), st["l1"].data_ptr(), st["l2"].data_ptr(), p2.to(dev).contiguous().data_ptr(), pred.data_ptr(),
+              st["csum"].data_ptr(), st["l1"].data_ptr(), st["l2"].data_ptr(), p2d.data_ptr(), pred.data_ptr(),
               wgt.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _close(wgt, want_w, 1e-5, "assignment weights")
     _close(pred, want_pred, 1e-5, "weighted targets")

@@ -205,9 +205,11 @@ def test_pe_mlp_max_register_chained_vs_exact_and_fp64(dev, W, B, N, S):
     idx[:, :, 0] = torch.arange(N, dtype=torch.int32)[None]
     L = W.pe["mlp"][0 if S == 32 else 1]
 
+    pts_d, idx_d = pts.to(dev), idx.to(dev)  # (named: a temporary's memory could be reused before the launch)
+
     def run():
         out = torch.full((B * N, 256), -7.0, device=dev)
-        _lib.call("sam6d_pe_mlp_max", pts.to(dev).data_ptr(), idx.to(dev).data_ptr(), B, N, S, L[0]["w"].data_ptr(),
+        _lib.call("sam6d_pe_mlp_max", pts_d.data_ptr(), idx_d.data_ptr(), B, N, S, L[0]["w"].data_ptr(),
                   L[0]["scale"].data_ptr(), L[0]["shift"].data_ptr(), L[1]["w"].data_ptr(), L[1]["scale"].data_ptr(),
                   L[1]["shift"].data_ptr(), L[2]["w"].data_ptr(), L[2]["scale"].data_ptr(), L[2]["shift"].data_ptr(),
                   out.data_ptr(), 256, 128, torch.cuda.current_stream().cuda_stream)
