@@ -337,17 +337,15 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   // fp32's own range; in-range tiles (everything the matching path produces itself) are untouched, so results stay independent of the
   // batch neighbours that share a tile.  All-zero operands are left alone.
   {
+    __shared__ float red[8];  // (its own words: no barrier needed against the staging buffers the other waves may still read)
     ma = wave_max_dpp(ma);
     mw = wave_max_dpp(mw);
-    __syncthreads();  // the staging buffers are free
-    float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) { red[wave] = ma; red[4 + wave] = mw; }
     __syncthreads();
     const float ta = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float tw = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     const bool bad = !(ta < 32768.0f) || !(tw < 32768.0f) || (ta > 0.f && ta < 0.015625f) || (tw > 0.f && tw < 0.015625f);
-    __syncthreads();
-    if (bad) {  // (uniform for the workgroup)
+    if (bad) {  // (uniform for the workgroup; the exact loop and the epilogue put their own barriers before they touch the LDS)
       float* As = reinterpret_cast<float*>(smem);
       gemm_exact_mainloop<BM, BN>(acc, A, W, M, N, K, lda, ldw, m0, n0, As, As + BM * GM_LD);
       __syncthreads();

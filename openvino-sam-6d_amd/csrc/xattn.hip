@@ -93,27 +93,38 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   }
   const float* kb = a.kv + (size_t)b * m * 512 + 64 * h;
   const float* vb = kb + 256;
+  // this thread's share of the head's keys and values (element e = t + 512 i: key e >> 6, channel e & 63) goes to registers in one
+  // burst of independent loads -- a loop that loads, reduces and stores element by element pays one memory round trip per element
+  constexpr int XA_EPT = (XA_MAXKEY * 64) / (XA_WAVES * 64);  // 26
+  float kreg[XA_EPT], vreg[XA_EPT];
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+    const bool ok = j < m;
+    kreg[i] = ok ? kb[(size_t)j * 512 + d] : 0.f;
+    vreg[i] = ok ? vb[(size_t)j * 512 + d] : 0.f;
+  }
   float mk = 0.f, mv = 0.f;
-  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
-    const int j = e >> 6, d = e & 63;
-    mk = fmaxf(mk, fabsf(kb[(size_t)j * 512 + d]));
-    mv = fmaxf(mv, fabsf(vb[(size_t)j * 512 + d]));
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    mk = fmaxf(mk, fabsf(kreg[i]));
+    mv = fmaxf(mv, fabsf(vreg[i]));
   }
   mk = wave_max_dpp(mk);
   mv = wave_max_dpp(mv);
   if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
-  for (int i = t; i < XA_K_BYTES / 4; i += XA_WAVES * 64) reinterpret_cast<unsigned*>(kimg)[i] = 0u;
   __syncthreads();
   float sk = 0.f, sv = 0.f;
 #pragma unroll
   for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
   sk = xa_pow2_scale(sk);
   sv = xa_pow2_scale(sv);
-  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
-    const int j = e >> 6, d = e & 63;
-    const float v = kb[(size_t)j * 512 + d] * sk;
+  // k_h image: every (key < 208, channel) slot is written (zeros beyond m), so no separate clearing pass
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
     _Float16 hi, lo;
-    sam6d_split_f16(v, hi, lo);
+    sam6d_split_f16(kreg[i] * sk, hi, lo);
     const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);  // half index in the hi plane (K = 64)
     _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
     const int ch = p >> 3, cl = 8 + (p >> 3);
@@ -192,14 +203,15 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   }
   __syncthreads();  // every wave is done with the Wq image
 
-  // ---- v_h^T image over the Wq region: row d, K = key (7 k-steps of 32, padded to 8), hi plane | lo plane (32 chunks further)
-  for (int i = t; i < XA_WQ_BYTES / 4; i += XA_WAVES * 64) reinterpret_cast<unsigned*>(regA)[i] = 0u;
+  // ---- v_h^T image over the Wq region: row d, K = key (7 k-steps of 32, padded to 8), hi plane | lo plane (32 chunks further).
+  // Cleared first: the key slots 208 .. 255 are multiplied by zero probabilities only, but must not hold NaN patterns.
+  for (int i = t; i < XA_WQ_BYTES / 16; i += XA_WAVES * 64) reinterpret_cast<uint4*>(regA)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  for (int e = t; e < m * 64; e += XA_WAVES * 64) {
-    const int j = e >> 6, d = e & 63;
-    const float v = vb[(size_t)j * 512 + d] * sv;
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
     _Float16 hi, lo;
-    sam6d_split_f16(v, hi, lo);
+    sam6d_split_f16(vreg[i] * sv, hi, lo);
     const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
     _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
     const int ch = p >> 3, cl = 32 + (p >> 3);
