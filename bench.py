@@ -9,8 +9,10 @@ proposals (weak scaling, proposals are independent) and the ranks all-gather the
 RCCL inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (rpe_score_kernel: the geometric self-attention
-scores of the six RPE layers, profiles/r01_step4_kernel_stats.csv), timed with HIP events on the launch stream inside the timed steps; `cpu_baseline` = the CPU oracle (a port of the reference's
-algorithm, oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
+scores of the six RPE layers, 21 % of the kernel time, profiles/r02_step3_kernel_stats.csv), timed with HIP events on the launch stream
+inside the timed steps; `roofline_dense_layer` (the fused dense linear-attention layer) and `roofline_fine_match` (similarity + soft
+assignment of the fine stage) the same way; `cpu_baseline` = the CPU oracle (a port of the reference's algorithm,
+oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -173,8 +175,9 @@ def main():
         ms = sorted(a.elapsed_time(b) for a, b in ev)
         k_ms = sum(ms) / max(1, len(ms))
         traffic = None  # HBM bytes per launch from the PMC passes recorded under profiles/ (not measured live)
+        tj = {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             traffic = tj["kernels"][kname if fused else "geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if B == B_PER_GPU else None
             if traffic is not None and fused:  # recorded for a 64-cloud launch; a micro-batch slice moves its share
                 mbk = int(os.environ.get("SAM6D_MICROBATCH", "1"))
@@ -214,26 +217,47 @@ def main():
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
-        # second roofline: the generic GEMM kernel has the largest total time of any kernel symbol (rocprof: 20 %); its dominant
-        # shape is the dense-token projection (2B x 2049 rows, K = N = 256), an HBM stream: algorithmic bytes = A read + C write
-        # (+ residual read) + weights, per launch, over the launches of the timed steps (HIP events on the launch stream).
-        gev = prof.get("gemm_dense_256", [])
-        gbytes = prof.get("gemm_dense_256_bytes", [])
-        roofline_gemm = None
-        if gev and len(gbytes) == len(gev):
-            g_ms = [a.elapsed_time(b) for a, b in gev]
-            g_gbs = sum(gbytes) / 1e9 / (sum(g_ms) * 1e-3)
-            g_traffic = None
+        # further rooflines (HIP events on the launch stream, inside the timed steps), traffic from the PMC passes under profiles/
+        def _tr(prefix):
             try:
-                gk = [k for k in tj["kernels"] if k.startswith("gemm_dense_256")]
-                g_traffic = tj["kernels"][gk[0]]["hbm_bytes_per_launch"] if (gk and B == B_PER_GPU) else None
+                k = [k for k in tj["kernels"] if k.startswith(prefix)]
+                return tj["kernels"][k[0]]["hbm_bytes_per_launch"] if (k and B == B_PER_GPU) else None
             except Exception:
-                g_traffic = None
-            roofline_gemm = {"bound": "hbm", "kernel": "gemm_nt_h3_kernel<128,128> on the dense-token projections (M = %d, K = N = 256, "
-                             "fp16x3 split-precision MFMA): %d launches per step" % (2 * B * 2049, len(gev) // max(1, args.steps)),
-                             "achieved": g_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g_gbs / PEAK_HBM_GBS, "traffic": g_traffic,
-                             "launch_ms": sum(g_ms) / len(g_ms), "launches_timed": len(g_ms),
-                             "algorithmic_mb_per_launch": sum(gbytes) / len(gbytes) / 1e6}
+                return None
+
+        extra = {}
+        lev = prof.get("linattn_layer", [])
+        if lev:
+            # the dense LinearTransformerLayer of the sparse-to-dense lift as ONE kernel (token_block_kernel<1>): 2B clouds x 2048 tokens,
+            # per token proj_q 256x256, head mix 4 x 64x64, linear 256x256, FFN 256 -> 512 -> 256 (fp32-equivalent flops, every product = 3
+            # fp16 MFMA products); algorithmic bytes = D read + D' written
+            l_ms = [a.elapsed_time(b) for a, b in lev]
+            ms1 = sum(l_ms) / len(l_ms)
+            tok = 2 * B * 2048
+            fl = tok * 2.0 * (2 * 256 * 256 + 256 * 64 + 2 * 256 * 512)
+            ach = fl / (ms1 * 1e-3) / 1e12
+            extra["roofline_dense_layer"] = {
+                "bound": "mfma", "kernel": "token_block_kernel<1> (sam6d_linattn_layer): one dense linear-attention layer over %d clouds, "
+                "%d launches per step" % (2 * B, len(lev) // max(1, args.steps)),
+                "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s", "frac": ach / (PEAK_FP16_MFMA_TFLOPS / 3.0),
+                "traffic": _tr("token_block_kernel<1>"), "launch_ms": ms1, "launches_timed": len(l_ms),
+                "algorithmic_gflop_per_launch": fl / 1e9, "algorithmic_mb_per_launch": 2 * tok * 256 * 4 / 1e6,
+                "hbm_gbs_algorithmic": 2 * tok * 256 * 4 / 1e9 / (ms1 * 1e-3)}
+        fev = prof.get("fine_match", [])
+        if fev:
+            # similarity + soft assignment of the fine stage (7 launches of finematch.hip): an HBM stream -- features read and written as
+            # fp16 hi/lo, E = exp(att - c) (B x 2049 x 2052 floats) written once and read twice
+            f_ms = [a.elapsed_time(b) for a, b in fev]
+            ms1 = sum(f_ms) / len(f_ms)
+            Eb = B * 2049 * 2052 * 4
+            feat = 2 * B * 2049 * 256 * 4
+            alg = feat + feat + feat + Eb + feat + Eb + Eb  # prep r + w, sim operands, E write, bg rows, labels read, assign read
+            gbs = alg / 1e9 / (ms1 * 1e-3)
+            extra["roofline_fine_match"] = {
+                "bound": "hbm", "kernel": "sam6d_fine_match (fm_prep / fm_sim / fm_bg / fm_labels / fm_assign + 2 merges), once per step",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "traffic": (tj.get("fine_match_total_bytes") if B == B_PER_GPU else None) if isinstance(tj, dict) else None,
+                "launch_ms": ms1, "launches_timed": len(f_ms), "algorithmic_mb_per_launch": alg / 1e6}
         res = {
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,11 +268,11 @@ def main():
                                    "RCCL all-gather of 13 floats/proposal" % world,
                        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                        "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA",
-                       "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding"},
+                       "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding",
+                       "fused_blocks": (os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1" and split)},
             "roofline": roofline,
         }
-        if roofline_gemm is not None:
-            res["roofline_dense_gemm"] = roofline_gemm
+        res.update(extra)
         if args.cpu_proposals > 0 and world == 1:
             # host cores for the baseline: the GPU box gives a 1-GPU job a share of 16 cores (more threads only
             # oversubscribe the shared host: 256 threads ran the same port 20x slower)
