@@ -168,7 +168,8 @@ def main():
 
     if rank == 0:
         total = world * B * args.steps
-        split = _lib.load().sam6d_get_matmul_mode() == 1
+        mode = _lib.load().sam6d_get_matmul_mode()
+        split = mode >= 1
         fused = split and os.environ.get("SAM6D_FUSED_RPE", "1") == "1"
         kname = "rpe_score_kernel" if fused else "geo_embed_kernel"
         ev = prof.get(kname, [])
@@ -194,7 +195,7 @@ def main():
             clouds = 2 * ((B + mb - 1) // mb)  # the batch runs as `mb` slices on `mb` streams: one launch covers one slice
             flop = clouds * 197 * RPE_FLOP_PER_QUERY
             achieved = flop / (k_ms * 1e-3) / 1e12 if ev else None
-            peak = PEAK_FP16_MFMA_TFLOPS / 3.0
+            peak = PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0)
             ref_flop = clouds * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
             roofline = {"bound": "mfma",
                         "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16x3 split = 3 MFMA products per fp32 product), "
@@ -204,7 +205,7 @@ def main():
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": flop / 1e9,
-                        "executed_mfma_tflops": (3.0 * achieved * (208.0 / 197.0)) if achieved else None,
+                        "executed_mfma_tflops": ((1.0 if mode == 2 else 3.0) * achieved * (208.0 / 197.0)) if achieved else None,
                         "reference_formulation_gflop_per_launch": ref_flop / 1e9,
                         "reference_formulation_tflops": (ref_flop / (k_ms * 1e-3) / 1e12) if ev else None,
                         "fp16_mfma_peak": PEAK_FP16_MFMA_TFLOPS}
@@ -239,7 +240,8 @@ def main():
             extra["roofline_dense_layer"] = {
                 "bound": "mfma", "kernel": "token_block_kernel<1> (sam6d_linattn_layer): one dense linear-attention layer over %d clouds, "
                 "%d launches per step" % (2 * B, len(lev) // max(1, args.steps)),
-                "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s", "frac": ach / (PEAK_FP16_MFMA_TFLOPS / 3.0),
+                "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0), "unit": "TFLOP/s",
+                "frac": ach / (PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0)),
                 "traffic": _tr("token_block_kernel<1>"), "launch_ms": ms1, "launches_timed": len(l_ms),
                 "algorithmic_gflop_per_launch": fl / 1e9, "algorithmic_mb_per_launch": 2 * tok * 256 * 4 / 1e6,
                 "hbm_gbs_algorithmic": 2 * tok * 256 * 4 / 1e9 / (ms1 * 1e-3)}
@@ -262,12 +264,14 @@ def main():
             "metric": "proposals/sec through PEM match+SVD (B=32, 2048 pts); pose Δ vs CPU ref",
             "value": total / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (fp16x3 split-precision MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
+            "dtype": ("f16 (single-product fp16 MFMA, fp32 accumulate; geometry fp32)" if mode == 2 else
+                      "f32 (fp16x3 split-precision MFMA, fp32 accumulate)" if split else "f32"), "data": "synthetic",
             "config": {"workload": "PEM batch=%d proposals/GPU, 2048 scene + 2048 model pts, 1024 CAD pts, random-init weights "
                                    "(SURVEY 8d config 2)" % B, "proposals_per_gpu": B, "parallelism": "proposal-sharded x%d, "
                                    "RCCL all-gather of 13 floats/proposal" % world,
                        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
-                       "matmul": "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA",
+                       "matmul": ("fp16 single-product MFMA, fp32 accumulate (~1e-3 rel.; BASELINE config 5 arithmetic)" if mode == 2 else
+                                  "fp16x3 split-precision MFMA, fp32 accumulate (~1e-6 rel.)" if split else "exact fp32 MFMA"),
                        "rpe": "fused (Chebyshev basis, no embedding tensor)" if fused else "materialised embedding",
                        "fused_blocks": (os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1" and split)},
             "roofline": roofline,

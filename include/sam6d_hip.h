@@ -74,7 +74,8 @@ int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, i
 /* C = act(((A . W^T) / divisor) * colscale + bias) + residual  on the fp32 matrix cores.
  * replaces nn.Linear / 1x1-conv call sites (PEM/model/transformer.py:127-129,186-188,390-393,548-550;
  * PEM/model/coarse_point_matching.py:35-38) and the similarity contraction (PEM/utils/model_utils.py:144-150).
- * A (M,K) lda; W (N,K) ldw; C (M,N) ldc; residual (M,N) ldr or NULL; bias/colscale (N) or NULL; act 0 none / 1 ReLU;
+ * A (M,K) lda; W (N,K) ldw; C (M,N) ldc; residual (M,N) ldr or NULL; bias/colscale (N) or NULL; act 0 none / 1 ReLU,
+ * + 16 marks a geometric operand (the proj_p / Chebyshev folds of the RPE query) that keeps the fp16 x3 split in matmul mode 2;
  * `batch` independent problems with strides sA/sW/sC/sR (floats).  divisor = 1 disables the division. */
 int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                   float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
@@ -85,8 +86,11 @@ int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int
                      long sA, long sW, long sC, int batch2, long sA2, long sW2, long sC2, void* stream);
 
 /* Matrix-core arithmetic of gemm_nt / geo_embed: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
- * 1 = fp16 x3 split (x = hi + lo in fp16, 3 MFMAs, ~1e-6 relative; default).  Both replace the same F.linear call
- * sites (PEM/model/transformer.py:127-129); the mode is process-wide.
+ * 1 = fp16 x3 split (x = hi + lo in fp16, 3 MFMAs, ~1e-6 relative; default), 2 = fp16 single product (hi . hi only, fp32
+ * accumulate, ~1e-3 relative: the "fp16 MFMA GeometricTransformer" arithmetic of BASELINE.json config 5; applies to sam6d_gemm_nt,
+ * the fused block / cross-attention / fine-match kernels and the RPE score contraction; the geometric indices, the outlier embedding
+ * rows and the PE MLP keep the split).  All replace the same F.linear call sites (PEM/model/transformer.py:127-129); the mode is
+ * process-wide.
  * Operand range in mode 1: ANY finite fp32 input is accepted.  sam6d_gemm_nt keeps the split for tiles whose operands lie in
  * [2^-6, 2^15) in magnitude (by their tile maximum; what the matching path produces itself is always there) and recomputes a tile
  * whose A or W block leaves that range with the exact fp32 MFMA loop of mode 0, so |x| >= 65520 cannot become inf - inf and uniformly

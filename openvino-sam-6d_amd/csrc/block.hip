@@ -185,25 +185,27 @@ __device__ __forceinline__ void tb_load_step(const unsigned (&a)[4], tb_u32x4* f
 #define TB_FD 1
 template <int KS, int S>
 __device__ __forceinline__ void tb_mma_step(f32x4& acc0, f32x4& acc1, const unsigned (&a)[4], const half8* __restrict__ xh,
-                                            const half8* __restrict__ xl, tb_u32x4 (&f)[TB_FD + 1][4]) {
+                                            const half8* __restrict__ xl, tb_u32x4 (&f)[TB_FD + 1][4], bool half) {
   constexpr int cur = S % (TB_FD + 1);
   if constexpr (S + TB_FD < KS) tb_load_step<KS, S + TB_FD>(a, f[(S + TB_FD) % (TB_FD + 1)]);
   constexpr int newer = (KS - 1 - S) < TB_FD ? (KS - 1 - S) : TB_FD;  // steps requested after this one
   tb_wait<4 * newer>(f[cur][0], f[cur][1], f[cur][2], f[cur][3]);
   const half8 h0 = __builtin_bit_cast(half8, f[cur][0]), l0 = __builtin_bit_cast(half8, f[cur][1]);
   const half8 h1 = __builtin_bit_cast(half8, f[cur][2]), l1 = __builtin_bit_cast(half8, f[cur][3]);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, xh[S], acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, xh[S], acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xl[S], acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xl[S], acc1, 0, 0, 0);
+  if (!half) {  // (launch-uniform) matmul mode 2 keeps the hi . hi product only
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, xh[S], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, xh[S], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xl[S], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xl[S], acc1, 0, 0, 0);
+  }
   acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xh[S], acc0, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xh[S], acc1, 0, 0, 0);
-  if constexpr (S + 1 < KS) tb_mma_step<KS, S + 1>(acc0, acc1, a, xh, xl, f);
+  if constexpr (S + 1 < KS) tb_mma_step<KS, S + 1>(acc0, acc1, a, xh, xl, f, half);
 }
 // `panel`: LDS byte address of the panel; rows fr (first out tile) and fr + 16 (second)
 template <int KS>
 __device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, unsigned panel, const half8* __restrict__ xh,
-                                       const half8* __restrict__ xl, int fr, int fg) {
+                                       const half8* __restrict__ xl, int fr, int fg, bool half) {
   const unsigned rowbase = panel + fr * TB_ROWB(KS);
   const unsigned a[4] = {rowbase + (((0 + fg) ^ fr) << 4), rowbase + (((4 + fg) ^ fr) << 4), rowbase + (((8 + fg) ^ fr) << 4),
                          rowbase + (((12 + fg) ^ fr) << 4)};
@@ -211,7 +213,7 @@ __device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, unsigned panel,
   tb_load_step<KS, 0>(a, f[0]);
   if constexpr (TB_FD >= 2 && KS >= 2) tb_load_step<KS, 1>(a, f[1]);
   if constexpr (TB_FD >= 3 && KS >= 3) tb_load_step<KS, 2>(a, f[2]);
-  tb_mma_step<KS, 0>(acc0, acc1, a, xh, xl, f);
+  tb_mma_step<KS, 0>(acc0, acc1, a, xh, xl, f, half);
 }
 
 // a token's channels live in the four lanes 16 apart (g = lane >> 4): reductions over the token
@@ -291,6 +293,7 @@ struct TbArgs {
   long M;                 // mode 0: rows
   int I, row0, tiles_per_b;  // mode 1: rows per cloud, first row handled, tiles per cloud
   float eps;
+  int half;               // 1: fp16 single product (matmul mode 2)
 };
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   float* ksm = cst + TC_N;                                                    // 256 floats (mode 1)
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   typedef TbSched<MODE, WAVES> SCH;
+  const bool half = a.half != 0;
   const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pan;
 
   // ---- which rows
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     tb_static_for<0, 8>([&](auto J) {
       constexpr int j = decltype(J)::value;
       const unsigned p = next_panel(std::integral_constant<int, j>{});
-      tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg);
+      tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
     });
     {
       const float inv = cst[TC_SC + 0] * (1.0f / sx);
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     tb_static_for<0, 8>([&](auto J) {
       constexpr int j = decltype(J)::value;
       const unsigned p = next_panel(std::integral_constant<int, 8 + j>{});
-      tb_mma<2>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg);
+      tb_mma<2>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg, half);
     });
     {
       const float inv = a.kvinv[b] * (1.0f / sx);
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   tb_static_for<0, 8>([&](auto J) {
     constexpr int j = decltype(J)::value;
     const unsigned p = next_panel(std::integral_constant<int, P0 + j>{});
-    tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg);
+    tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
   });
   {
     const float inv = cst[TC_SC + 1] * (1.0f / sx);
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
         constexpr int u = decltype(U)::value;
         const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + u>{});
         f32x4 ha[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        tb_mma<8>(ha[0], ha[1], p, xh, xl, fr, fg);
+        tb_mma<8>(ha[0], ha[1], p, xh, xl, fr, fg, half);
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
           const float4 be = *reinterpret_cast<const float4*>(cst + TC_BEXP + 128 * c + 32 * u + 16 * w + 4 * fg);
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
       tb_static_for<0, 8>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + 4 + j>{});
-        tb_mma<4>(acc[2 * j], acc[2 * j + 1], p, hh, hl, fr, fg);
+        tb_mma<4>(acc[2 * j], acc[2 * j + 1], p, hh, hl, fr, fg, half);
       });
     });
   }
@@ -649,7 +653,8 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   if (M == 0) return 0;
   int rc = tb_set_attr();
   if (rc) return rc;
-  TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps};
+  TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps,
+           sam6d_get_matmul_mode() == 2 ? 1 : 0};
   if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<0, 8, 4>), dim3((unsigned)((M + 127) / 128)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else
@@ -668,7 +673,8 @@ extern "C" int sam6d_linattn_layer(const float* D, const void* wimage, const flo
   const int tok = 16 * tb_shape();
   const int tiles = (I - row0 + tok - 1) / tok;
   SAM6D_REQUIRE((long)B * tiles < 2147483647L, "linattn_layer: too many tiles");
-  TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps};
+  TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps,
+           sam6d_get_matmul_mode() == 2 ? 1 : 0};
   if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<1, 8, 4>), dim3((unsigned)(B * tiles)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else

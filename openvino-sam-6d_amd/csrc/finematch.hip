@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void fm_prep_kernel(const float* __restrict__ 
 #define FM_LD 40  // halves per LDS row (80 B): the ds_read_b128 fragment reads of 16 consecutive rows are conflict-free
 __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B,
                                                      float k1, float k2, float* __restrict__ E, float* __restrict__ rowpart,
-                                                     float* __restrict__ colpart) {
+                                                     float* __restrict__ colpart, int half) {
   __shared__ __attribute__((aligned(16))) _Float16 smem[4 * 128 * FM_LD];  // 40 KB; reused by the epilogue's transpose slabs
   _Float16* Ah = smem;
   _Float16* Al = Ah + 128 * FM_LD;
@@ -133,8 +133,10 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (!half) {  // (launch-uniform) matmul mode 2 keeps the hi . hi product only
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -464,7 +466,8 @@ extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const 
   const float log2e = 1.4426950408889634f;
   const float k1 = log2e / (FM_OPSCALE * FM_OPSCALE * temp), k2 = log2e / temp;
   hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, fh, fl);
-  hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * 256)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart);
+  hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * 256)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
+                     sam6d_get_matmul_mode() == 2 ? 1 : 0);
   hipLaunchKernelGGL(fm_bg_kernel, dim3(17, B), dim3(256), 0, s, fh, fl, B, k1, k2, E);
   hipLaunchKernelGGL(fm_merge_sums_kernel, dim3(9, B), dim3(256), 0, s, rowpart, colpart, E, rsum, csum);
   hipLaunchKernelGGL(fm_labels_kernel, dim3(FM_SLABS, B), dim3(256), 0, s, E, rsum, csum, label1, pbest, pidx);

@@ -149,7 +149,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                                                       int K, long lda, long ldw, long ldc, long ldr, long sA, long sW, long sC,
                                                       long sR, float divisor, int act, Batch2 b2) {
   constexpr int TM = BM / 64, TN = BN / 64;  // MFMA tiles per wave
-  constexpr int RA = BM / 64, RB = BN / 64;  // float4 staging loads per thread
   __shared__ float As[BM * GM_LD];
   __shared__ float Bs[BN * GM_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
-                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide) {
+                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide, int half) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RA = BM / 32, RB = BN / 32;  // float4 staging loads per thread (32 rows x 8 float4 per pass)
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * H_LD];  // also the epilogue's transpose slabs
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
       half4 hi, lo;
       split4(va[u], hi, lo);
       *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
-      *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
+      if (!half) *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
@@ -304,10 +303,25 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
       half4 hi, lo;
       split4(vb[u], hi, lo);
       *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
-      *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
+      if (!half) *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
     }
     __syncthreads();
     if (k0 + H_BK < K) fetch(k0 + H_BK);
+    if (half) {  // single product: hi halves only (workgroup-uniform branch)
+#pragma unroll
+      for (int ks = 0; ks < H_BK; ks += 16) {
+        half8 ah[TM], bh[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < H_BK; ks += 16) {
       half8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -435,10 +449,11 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
     }
 }
 
-// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp16 x3 split (default).  Process-wide; set before launching.
+// 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp16 x3 split (default), 2 = fp16 single product (a_hi . b_hi only, fp32
+// accumulate: the reduced-precision variant of BASELINE.json config 5, ~1e-3 relative).  Process-wide; set before launching.
 static int g_matmul_mode = 1;
 extern "C" int sam6d_set_matmul_mode(int mode) {
-  SAM6D_REQUIRE(mode == 0 || mode == 1, "set_matmul_mode: 0 (exact fp32 MFMA) or 1 (fp16 x3 split)");
+  SAM6D_REQUIRE(mode == 0 || mode == 1 || mode == 2, "set_matmul_mode: 0 (exact fp32 MFMA), 1 (fp16 x3 split) or 2 (fp16 single product)");
   g_matmul_mode = mode;
   return 0;
 }
@@ -451,7 +466,9 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   SAM6D_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0 && b2.n2 >= 1, "gemm_nt: bad sizes M=%d N=%d K=%d batch=%d x %d", M, N,
                 K, batch, b2.n2);
   SAM6D_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm_nt: leading dimension smaller than the row length");
-  SAM6D_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (ReLU)");
+  const int keep_split = act & 16;  // geometric operand: stays at fp16 x3 in matmul mode 2 (sam6d_hip.h)
+  act &= ~16;
+  SAM6D_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (ReLU), optionally + 16");
   SAM6D_REQUIRE((long)batch * b2.n2 <= 65535, "gemm_nt: batch (x batch2) must be <= 65535");
   if (M == 0 || N == 0 || batch == 0) return 0;
   const int nz = batch * b2.n2;
@@ -469,13 +486,14 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
 #define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
                      sC, sR, divisor, act, b2, ##__VA_ARGS__)
-  if (g_matmul_mode == 1 && K >= 32) {
+  if (g_matmul_mode >= 1 && K >= 32) {
+    const int half = (g_matmul_mode == 2 && !keep_split) ? 1 : 0;
     // 16-byte epilogue accesses need 4-float alignment of every row start and of the per-column vectors
     const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (b2.sC2 & 3) == 0 && (((size_t)C) & 15) == 0 &&
                       (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (b2.sR2 & 3) == 0 && (((size_t)residual) & 15) == 0)) &&
                       (!bias || (((size_t)bias) & 15) == 0) && (!colscale || (((size_t)colscale) & 15) == 0))
                          ? 1 : 0;
-    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>), wide); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>), wide);
+    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>), wide, half); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>), wide, half);
   } else {
     if (big) GEMM_LAUNCH((gemm_nt_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_kernel<64, 64>));
   }
@@ -659,7 +677,7 @@ extern "C" int sam6d_gemm_ln256(const float* A, const float* W, const float* bia
   SAM6D_REQUIRE(M >= 0 && K >= 32 && (K % 32) == 0, "gemm_ln256: K must be a positive multiple of 32 (got %d)", K);
   SAM6D_REQUIRE(lda >= K && ldw >= K && ldy >= 256 && (!residual || ldr >= 256), "gemm_ln256: leading dimension too small");
   SAM6D_REQUIRE(((lda | ldw) & 3) == 0 && ((((size_t)A) | ((size_t)W)) & 15) == 0, "gemm_ln256: A and W rows must be 16-byte aligned");
-  SAM6D_REQUIRE(g_matmul_mode == 1, "gemm_ln256: split-precision mode only (use sam6d_gemm_nt + sam6d_layernorm256 in mode 0)");
+  SAM6D_REQUIRE(g_matmul_mode >= 1, "gemm_ln256: split-precision mode only (use sam6d_gemm_nt + sam6d_layernorm256 in mode 0)");
   if (M == 0) return 0;
   hipLaunchKernelGGL(gemm_ln_h3_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, A, W, bias, residual, gamma,
                      beta, Y, M, K, lda, ldw, ldr, ldy, eps);

@@ -319,7 +319,7 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
   if (total == 0) return 0;
   const long per_block = PM_WAVES * PM_PPW;
   const dim3 grid((unsigned)((total + per_block - 1) / per_block));
-  if (sam6d_get_matmul_mode() == 1) {
+  if (sam6d_get_matmul_mode() >= 1) {
     SAM6D_REQUIRE(total < (1l << 31) / 64, "pe_mlp_max: B*N too large for 32-bit point ids (%ld)", total);
     const size_t lds = (size_t)PH_WBYTES;
     static unsigned long long attr_h3 = 0;

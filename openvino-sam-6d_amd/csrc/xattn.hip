@@ -48,7 +48,7 @@ __device__ __forceinline__ float xa_tok_sum(float s) {
 // 16-byte chunks further), chunk c stored at (c & ~15) | ((c ^ row) & 15).
 template <int ROWB, int LOCH, int KS>
 __device__ __forceinline__ void xa_mma(f32x4& acc, const unsigned char* __restrict__ img, int r0, const half8* __restrict__ xh,
-                                       const half8* __restrict__ xl, int fr, int fg) {
+                                       const half8* __restrict__ xl, int fr, int fg, bool half) {
   const int row = r0 + fr;
   const unsigned char* rb = img + (size_t)row * ROWB;
 #pragma unroll
@@ -56,8 +56,10 @@ __device__ __forceinline__ void xa_mma(f32x4& acc, const unsigned char* __restri
     const int ch = 4 * s + fg, cl = LOCH + 4 * s + fg;
     const half8 ah = *reinterpret_cast<const half8*>(rb + (((ch & ~15) | ((ch ^ row) & 15)) << 4));
     const half8 al = *reinterpret_cast<const half8*>(rb + (((cl & ~15) | ((cl ^ row) & 15)) << 4));
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[s], acc, 0, 0, 0);
+    if (!half) {  // (launch-uniform) matmul mode 2 keeps the hi . hi product only
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[s], acc, 0, 0, 0);
+    }
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[s], acc, 0, 0, 0);
   }
 }
@@ -70,6 +72,7 @@ struct XaArgs {
   float* out;         // (B, n, 256)
   int n, m;
   float inv_wq;       // 1 / pack scale of Wq
+  int half;           // 1: fp16 single product (matmul mode 2)
 };
 
 __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   const int h = blockIdx.x, b = blockIdx.y;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   const int n = a.n, m = a.m;
+  const bool half = a.half != 0;
 
   // ---- Wq_h image by LDS-DMA (64 pieces of 1 KiB), k_h image built here from the fp32 keys
   {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          xa_mma<1024, 32, 8>(acc[i], regA, 16 * i, xh, xl, fr, fg);
+          xa_mma<1024, 32, 8>(acc[i], regA, 16 * i, xh, xl, fr, fg, half);
         }
         // q = acc / (s_wq sx) + bq, times 1/8 (the softmax scale 1/sqrt(64): a power of two, folded here)
         const float inv = a.inv_wq * (1.0f / sx) * 0.125f;
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
 #pragma unroll
       for (int i = 0; i < XA_NT; ++i) {
         s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        xa_mma<256, 8, 2>(s[i], kimg, 16 * i, qh[gi], ql[gi], fr, fg);
+        xa_mma<256, 8, 2>(s[i], kimg, 16 * i, qh[gi], ql[gi], fr, fg, half);
       }
       // logits (already / 8), keys >= m masked; softmax over the token's keys
       const float inv = inv_k * (1.0f / sq[gi]);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        xa_mma<1024, 32, 7>(o[i], regA, 16 * i, ph, pl, fr, fg);
+        xa_mma<1024, 32, 7>(o[i], regA, 16 * i, ph, pl, fr, fg, half);
       }
       const int tok = grp * 16 + fr;
       if (tok < n) {
@@ -299,7 +303,7 @@ extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void
       return (int)e;
     }
   }
-  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale};
+  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_get_matmul_mode() == 2 ? 1 : 0};
   hipLaunchKernelGGL(xattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention");
 }

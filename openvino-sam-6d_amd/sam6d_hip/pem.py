@@ -292,7 +292,7 @@ def _post_attention(hidden, x2d, L):
         return out
     # SAM6D_FUSED_LN=1: projection + residual + LayerNorm in one launch (sam6d_gemm_ln256).  Off by default: measured 1 % slower
     # than the two launches (64-row tiles at 184 registers and 4-byte stores cost what the saved LayerNorm pass gives back).
-    if _lib.load().sam6d_get_matmul_mode() == 1 and os.environ.get("SAM6D_FUSED_LN", "0") == "1":
+    if _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_FUSED_LN", "0") == "1":
         y = gemm_ln(hidden, L["lin"], x2d, L["n1"])
         h = linear(y, L["exp"], act=1)
         return gemm_ln(h, L["sq"], y, L["n2"])
@@ -304,7 +304,7 @@ def _post_attention(hidden, x2d, L):
 def _fused_block():
     """The fused transformer-block kernels (csrc/block.hip) serve the split-precision mode; SAM6D_FUSED_BLOCK=0 keeps the
     launch-per-op path (also what matmul mode 0, the exact fp32 MFMA reference arithmetic, uses)."""
-    return _lib.load().sam6d_get_matmul_mode() == 1 and os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1"
+    return _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1"
 
 
 def gemm_ln(x, lin, residual, norm, eps=1e-5):
@@ -347,13 +347,13 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     flag = knn.data_ptr() + 4 * B * n * angle_k
     factor_a = 180.0 / (sigma_a * math.pi)
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
-    if _lib.load().sam6d_get_matmul_mode() == 1:
+    if _lib.load().sam6d_get_matmul_mode() >= 1:
         lst = _empty((B * n * n + 1,), points_bg, torch.int32)  # [count | pair ids outside the Chebyshev range]
         pos = _empty((B * n * n,), points_bg, torch.int32)  # pair -> list slot or -1
         with _Timed("geo_embed_kernel"):
             _lib.call("sam6d_geo_embed_cheb", _p(idx), B * n * n, geo_cheb_packed(W).data_ptr(), float(GEO_XMAX), _p(W.div_term),
                       geo_packed(W).data_ptr(), _p(W.geo_d.b), _p(W.geo_a.b), C, flag, _p(pos), _p(lst), _p(out), _s())
-    if _lib.load().sam6d_get_matmul_mode() == 1:
+    if _lib.load().sam6d_get_matmul_mode() >= 1:
         # indices beyond the fast sincos range (flag set on the device): this launch redoes the call exactly; otherwise
         # it returns immediately
         _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
@@ -472,9 +472,10 @@ def rpe_self_layer_fused(x, G, L):
     x2 = x.reshape(M, C)
     qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
     qp = _empty((M, H * C), x)
-    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C)
+    # (act 16: the two folds of the geometric embedding into the query stay at fp16 x3 in matmul mode 2 -- "fp32 geometry")
+    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C, act=16)
     qd = _empty((M * H, 32), x)
-    gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32)
+    gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32, act=16)
     ldp = (n + 3) // 4 * 4
     qk = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
@@ -875,7 +876,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     fp32 instructions since).  scratch/dbg_ov.py: 0 of 60 two-slice runs differ from the serial result."""
     B = dense_pm.shape[0]
     mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
-    fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() == 1
+    fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() >= 1
     fused = fused and not return_aux
 
     overlap = cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1")
@@ -955,11 +956,11 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
 
     dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
     if mb <= 1 or B < 8 * mb or return_aux:
-        if _lib.load().sam6d_get_matmul_mode() == 1:
+        if _lib.load().sam6d_get_matmul_mode() >= 1:
             geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
         return rest(prepare(0, B, side_key=0), 0, B, 0)
     main = torch.cuda.current_stream()
-    if _lib.load().sam6d_get_matmul_mode() == 1:
+    if _lib.load().sam6d_get_matmul_mode() >= 1:
         geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
     per = (B + mb - 1) // mb
     spans = [(i * per, min(B, (i + 1) * per)) for i in range(mb)]

@@ -219,3 +219,42 @@ def test_shared_template_equals_repeated_form(dev, W):
     other[B - 1, 2047, 255] += 1.0
     assert not pem.template_is_shared(d["dense_po"], other)
     assert not pem.template_is_shared(d["dense_po"][:1], d["dense_fo"][:1])
+
+
+# ------------------------------------------------------------------------------------------- config 5: fp16 single-product mode
+def test_config5_fp16_single_product_mode(dev, sd):
+    """BASELINE.json config 5: the GeometricTransformer contractions with ONE fp16 MFMA product (matmul mode 2: no lo halves, fp32
+    accumulate, fp32 geometry) and a 4096-point fine stage.  Not the 1e-4 contract: the deviation from the default (fp16x3) arithmetic
+    is MEASURED here and bounded loosely -- GEMM ~1e-3 of the result scale, poses on the known-answer scene a few 1e-3."""
+    import math
+    from sam6d_hip import _lib, pem, synth
+    W = pem.PemWeights(sd, dev)
+    g = torch.Generator().manual_seed(55)
+    A = torch.randn(900, 256, generator=g).to(dev)
+    Wt = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    want = A.double().cpu() @ Wt.double().cpu().t()
+    inp = synth.kat_inputs(B=2, seed=5, n_dense=4096)
+    d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    prev = _lib.load().sam6d_get_matmul_mode()
+    res = {}
+    try:
+        for mode in (1, 2):
+            _lib.call("sam6d_set_matmul_mode", mode)
+            out = torch.empty(900, 256, device=dev)
+            pem.gemm(A, Wt, None, out, 900, 256, 256, 256, 256, 256)
+            gerr = float((out.cpu().double() - want).abs().max()) / float(want.abs().max())
+            R, t, s = pem.pem_match(*[d[k] for k in keys], W, d["rand"])
+            torch.cuda.synchronize()
+            res[mode] = (gerr, R.cpu(), t.cpu(), s.cpu())
+    finally:
+        _lib.call("sam6d_set_matmul_mode", prev)
+    g1, R1, t1, s1 = res[1]
+    g2, R2, t2, s2 = res[2]
+    dR = float((R1 - R2).abs().max()); dt = float((t1 - t2).abs().max()); ds = float((s1 - s2).abs().max())
+    print("\nconfig 5 (fp16 single product, 4096-pt fine stage): GEMM rel. err %.2e (split: %.2e); pose vs split mode: dR %.2e dt %.2e "
+          "dscore %.2e" % (g2, g1, dR, dt, ds))
+    assert g1 < 4e-6 and 1e-5 < g2 < 5e-3, "mode 2 must really drop the lo halves (GEMM error %.2e)" % g2
+    # measured on MI355X: dR 1.3e-4, dt 9e-6, dscore 0 (with the two geometric folds of the RPE query kept at fp16 x3; with them in
+    # single precision too the coarse pose of this scene flipped: dR 0.9)
+    assert torch.isfinite(R2).all() and dR < 5e-3 and dt < 5e-3 and ds < 5e-2
