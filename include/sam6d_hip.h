@@ -80,6 +80,14 @@ int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, i
 int sam6d_gemm_nt(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                   float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
                   long sC, long sR, float divisor, int act, void* stream);
+/* sam6d_gemm_nt with the weight operand cut into fp16 hi / lo halves ONCE, at weight-load time: Wh / Wl = the two outputs of
+ * sam6d_split_f16(W, n, w_scale) -- same (N,K) layout, ldw and batch stride as W, w_scale a power of two that puts max |W| into
+ * [2^13, 2^14).  Staging the weight tile is then a copy instead of a per-k-step split (the same nn.Linear call sites,
+ * PEM/model/transformer.py:127-129,186-188,390-393,548-550).  W (fp32) is still required: out-of-range activation tiles are
+ * recomputed with the exact fp32 loop.  In matmul mode 0 this is sam6d_gemm_nt. */
+int sam6d_gemm_nt_w16(const float* A, const float* W, const void* Wh, const void* Wl, float w_scale, const float* bias,
+                      const float* colscale, const float* residual, float* C, int M, int N, int K, long lda, long ldw, long ldc,
+                      long ldr, int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream);
 /* sam6d_gemm_nt with a second (inner) batch level and no epilogue: problem (b1, b2) uses A + b1*sA + b2*sA2 etc.
  * (the per-cloud, per-head q.k^T and P.v products of the attention: PEM/model/transformer.py:137-149, 408-419). */
 int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int K, long lda, long ldw, long ldc, int batch,

@@ -219,12 +219,17 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
              (_Float16)(v.w - (float)h3)};
 }
 
-template <int BM, int BN>
+// WS: the weight operand arrives pre-split -- Wh / Wl = fp16 hi / lo of W * 2^e, same (N, K) layout and strides as W, cut once at
+// weight-load time (sam6d_split_f16) -- so staging it is a copy: the per-k-step VALU split of the weight tile (half of the
+// kernel's vector work at K = 256) disappears, and so does its range check (the pack scale puts max |W| into [2^13, 2^14)).
+template <int BM, int BN, bool WS>
 __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
-                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide, int half) {
+                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide, int half,
+                                                         const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
+                                                         float w_unscale) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RA = BM / 32, RB = BN / 32;  // float4 staging loads per thread (32 rows x 8 float4 per pass)
   __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * H_LD];  // also the epilogue's transpose slabs
@@ -238,6 +243,10 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   const int bz = zz / b2.n2, bi = zz % b2.n2;
   A += (size_t)bz * sA + (size_t)bi * b2.sA2;
   W += (size_t)bz * sW + (size_t)bi * b2.sW2;
+  if (WS) {
+    Wh += (size_t)bz * sW + (size_t)bi * b2.sW2;
+    Wl += (size_t)bz * sW + (size_t)bi * b2.sW2;
+  }
   C += (size_t)bz * sC + (size_t)bi * b2.sC2;
   if (residual) residual += (size_t)bz * sR + (size_t)bi * b2.sR2;
   const int m0 = tm_ * BM, n0 = tn_ * BN;
@@ -261,12 +270,34 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
   const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
 
   float4 va[RA], vb[RB];
+  half4 wbh[RB], wbl[RB];
+  const bool wvec = WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0);
+  auto fetch_w16 = [&](int k0) {  // pre-split weight rows: 8-byte loads of 4 halves
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const size_t o = (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk + k0;
+      if (wvec && k0 + H_BK <= K) {
+        wbh[u] = *reinterpret_cast<const half4*>(Wh + o);
+        wbl[u] = *reinterpret_cast<const half4*>(Wl + o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = (k0 + sk + e) < K;
+          wbh[u][e] = ok ? Wh[o + e] : (_Float16)0.f;
+          wbl[u][e] = ok ? Wl[o + e] : (_Float16)0.f;
+        }
+      }
+    }
+  };
   auto fetch = [&](int k0) {
+    if (WS) fetch_w16(k0);
     if (vec && k0 + H_BK <= K) {
 #pragma unroll
       for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
+      if (!WS) {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+        for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+      }
     } else {
       float tmp[4];
 #pragma unroll
@@ -275,11 +306,13 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? ap[u][k0 + e] : 0.f;
         va[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
       }
+      if (!WS) {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
+        for (int u = 0; u < RB; ++u) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
-        vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+          for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
+          vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        }
       }
     }
   };
@@ -299,9 +332,14 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
-      mw = fmaxf(fmaxf(mw, fabsf(vb[u].x)), fmaxf(fabsf(vb[u].y), fmaxf(fabsf(vb[u].z), fabsf(vb[u].w))));
       half4 hi, lo;
-      split4(vb[u], hi, lo);
+      if (WS) {
+        hi = wbh[u];
+        lo = wbl[u];
+      } else {
+        mw = fmaxf(fmaxf(mw, fabsf(vb[u].x)), fmaxf(fabsf(vb[u].y), fmaxf(fabsf(vb[u].z), fabsf(vb[u].w))));
+        split4(vb[u], hi, lo);
+      }
       *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
       if (!half) *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
     }
@@ -363,6 +401,13 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
       float* As = reinterpret_cast<float*>(smem);
       gemm_exact_mainloop<BM, BN>(acc, A, W, M, N, K, lda, ldw, m0, n0, As, As + BM * GM_LD);
       __syncthreads();
+    } else if (WS) {  // undo the weight pack scale (a power of two: exact)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= w_unscale;
     }
   }
   if (wide) {
@@ -461,7 +506,8 @@ extern "C" int sam6d_get_matmul_mode(void) { return g_matmul_mode; }
 
 static int gemm_launch(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                        float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
-                       long sC, long sR, Batch2 b2, float divisor, int act, void* stream) {
+                       long sC, long sR, Batch2 b2, float divisor, int act, void* stream, const void* Wh = nullptr,
+                       const void* Wl = nullptr, float w_scale = 1.0f) {
   SAM6D_REQUIRE(A && W && C, "gemm_nt: null pointer");
   SAM6D_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0 && b2.n2 >= 1, "gemm_nt: bad sizes M=%d N=%d K=%d batch=%d x %d", M, N,
                 K, batch, b2.n2);
@@ -493,7 +539,16 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
                       (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (b2.sR2 & 3) == 0 && (((size_t)residual) & 15) == 0)) &&
                       (!bias || (((size_t)bias) & 15) == 0) && (!colscale || (((size_t)colscale) & 15) == 0))
                          ? 1 : 0;
-    if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128>), wide, half); else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64>), wide, half);
+    const _Float16* wh = reinterpret_cast<const _Float16*>(Wh);
+    const _Float16* wl = reinterpret_cast<const _Float16*>(Wl);
+    const float wu = 1.0f / w_scale;
+    if (wh && wl) {
+      if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, true>), wide, half, wh, wl, wu);
+      else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64, true>), wide, half, wh, wl, wu);
+    } else {
+      if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, false>), wide, half, wh, wl, wu);
+      else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64, false>), wide, half, wh, wl, wu);
+    }
   } else {
     if (big) GEMM_LAUNCH((gemm_nt_kernel<128, 128>)); else GEMM_LAUNCH((gemm_nt_kernel<64, 64>));
   }
@@ -506,6 +561,15 @@ extern "C" int sam6d_gemm_nt(const float* A, const float* W, const float* bias, 
                              int batch, long sA, long sW, long sC, long sR, float divisor, int act, void* stream) {
   return gemm_launch(A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
                      Batch2{1, 0, 0, 0, 0, 0}, divisor, act, stream);
+}
+
+extern "C" int sam6d_gemm_nt_w16(const float* A, const float* W, const void* Wh, const void* Wl, float w_scale, const float* bias,
+                                 const float* colscale, const float* residual, float* C, int M, int N, int K, long lda, long ldw,
+                                 long ldc, long ldr, int batch, long sA, long sW, long sC, long sR, float divisor, int act,
+                                 void* stream) {
+  SAM6D_REQUIRE(Wh && Wl && w_scale > 0.f, "gemm_nt_w16: the pre-split weight halves and their scale are required");
+  return gemm_launch(A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
+                     Batch2{1, 0, 0, 0, 0, 0}, divisor, act, stream, Wh, Wl, w_scale);
 }
 
 extern "C" int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int K, long lda, long ldw, long ldc,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
+    "sam6d_gemm_nt_w16": [c_p] * 4 + [c_f] + [c_p] * 4 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_set_matmul_mode": [c_i],
     "sam6d_layernorm256": [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_f, c_p],
     "sam6d_gemm_ln256": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_f, c_p],

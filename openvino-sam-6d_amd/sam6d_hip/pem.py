@@ -48,10 +48,22 @@ def _empty(shape, like, dtype=torch.float32):
 
 # --------------------------------------------------------------------------------------------- weight packing
 class Linear:
-    __slots__ = ("w", "b")
+    __slots__ = ("w", "b", "_w16")
 
     def __init__(self, w, b):
         self.w, self.b = w.contiguous(), (b.contiguous() if b is not None else None)
+        self._w16 = None
+
+    def w16(self):
+        """(hi, lo, scale): the weight cut into fp16 halves once (sam6d_split_f16) for sam6d_gemm_nt_w16; scale = the power of
+        two that puts max |w| into [2^13, 2^14)."""
+        if self._w16 is None:
+            sc = _pow2_scale(self.w.abs().max())
+            hi = torch.empty(self.w.shape, dtype=torch.float16, device=self.w.device)
+            lo = torch.empty_like(hi)
+            _lib.call("sam6d_split_f16", _p(self.w), self.w.numel(), float(sc), hi.data_ptr(), lo.data_ptr(), _s())
+            self._w16 = (hi, lo, float(sc))
+        return self._w16
 
 
 TB_P256, TB_P128, TB_P64 = 32768, 16384, 8192  # panel bytes of csrc/block.hip (32 rows x K = 256 / 128 / 64, fp16 hi + lo)
@@ -110,6 +122,11 @@ def pack_token_block(L, q=None, scale=None):
     cst[2048:2304], cst[2304:2560] = L["n2"]
     cst[2560:2565] = torch.tensor([1.0 / s_q, 1.0 / s_lin, 1.0 / s_exp, 1.0 / (s_sq * s_h), s_h], device=dev)
     return dict(img=img, cst=cst, mode=mode)
+
+
+def split_w16(w):
+    """(hi, lo, scale) of a weight tensor for sam6d_gemm_nt_w16 (see Linear.w16)."""
+    return Linear(w, None).w16()
 
 
 def pack_cross_query(q):
@@ -187,6 +204,7 @@ class PemWeights:
             # proj_p folded into the query (attention.hip header): WpT[j, k] = Wp[k, j]; its bias cancels in softmax
             wpT=g(sa + ".proj_p.weight").t().contiguous(),
             **self._post(g, s))
+        self_l["wpT16"] = split_w16(self_l["wpT"])
         cross_l = dict(
             q=Linear(g(ca + ".proj_q.weight"), g(ca + ".proj_q.bias")),
             kv=Linear(torch.cat([g(ca + ".proj_k.weight"), g(ca + ".proj_v.weight")], 0),
@@ -247,8 +265,15 @@ def pack_pe(sd, device, pe):
 
 # ------------------------------------------------------------------------------------------------- primitives
 def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, residual=None, r_off=0, ldr=0,
-         colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0):
+         colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0, w16=None):
+    """w16 = Linear.w16() of the weight `W` belongs to: the pre-split halves are used in the split-precision modes."""
     def launch():
+        if w16 is not None and K >= 32 and _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_W16", "1") == "1":
+            hi, lo, sc = w16
+            _lib.call("sam6d_gemm_nt_w16", _p(A, a_off), _p(W, w_off), hi.data_ptr() + 2 * w_off, lo.data_ptr() + 2 * w_off, sc, _p(bias),
+                      _p(colscale), _p(residual, r_off), _p(out, c_off), M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
+                      float(divisor), act, _s())
+            return
         _lib.call("sam6d_gemm_nt", _p(A, a_off), _p(W, w_off), _p(bias), _p(colscale), _p(residual, r_off), _p(out, c_off),
                   M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR, float(divisor), act, _s())
 
@@ -267,7 +292,7 @@ def linear(x2d, lin, *, act=0, residual=None, out=None):
     N = lin.w.shape[0]
     if out is None:
         out = _empty((M, N), x2d)
-    gemm(x2d, lin.w, lin.b, out, M, N, K, K, K, N, residual=residual, ldr=N, act=act)
+    gemm(x2d, lin.w, lin.b, out, M, N, K, K, K, N, residual=residual, ldr=N, act=act, w16=lin.w16())
     return out
 
 
@@ -422,7 +447,7 @@ def geo_packed(W):
 class GeoContext:
     """What the fused RPE attention needs instead of the (B,n,n,256) embedding tensor: the per-pair embedding indices, the
     map pair -> stored row for the pairs outside the Chebyshev range, those rows, and the packed coefficient matrices."""
-    __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "dcT", "keep")
+    __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "dcT", "dcT16", "keep")
 
 
 def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
@@ -445,6 +470,7 @@ def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     img = geo_cheb_packed(W)
     G.wa_cheb = img.data_ptr() + C * 144  # the proj_a half of the [mat][col][144 B] image
     G.dcT = geo_dcT(W)
+    G.dcT16 = geo_dcT16(W)
     G.keep = (knn, lst, img)
     return G
 
@@ -456,6 +482,13 @@ def geo_dcT(W):
         c = cheb_coefficients(W.geo_d.w, W.div_term)  # (256, 32) float64
         d = torch.from_numpy(c.T.copy()).to(device=W.geo_d.w.device, dtype=torch.float32).contiguous()
         W._geo_dcT = d
+    return d
+
+
+def geo_dcT16(W):
+    d = getattr(W, "_geo_dcT16", None)
+    if d is None:
+        d = W._geo_dcT16 = split_w16(geo_dcT(W))
     return d
 
 
@@ -473,9 +506,9 @@ def rpe_self_layer_fused(x, G, L):
     qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
     qp = _empty((M, H * C), x)
     # (act 16: the two folds of the geometric embedding into the query stay at fp16 x3 in matmul mode 2 -- "fp32 geometry")
-    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C, act=16)
+    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C, act=16, w16=L.get("wpT16"))
     qd = _empty((M * H, 32), x)
-    gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32, act=16)
+    gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32, act=16, w16=G.dcT16)
     ldp = (n + 3) // 4 * 4
     qk = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
@@ -500,7 +533,7 @@ def rpe_self_layer(x, E, L):
     qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
     qp = _empty((M, H * C), x)
     # qp[:, h, :] = q_h @ Wp[h*64:(h+1)*64, :]  -- 4 head problems as one batched launch
-    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C)
+    gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C, w16=L.get("wpT16"))
     hid = _empty((M, C), x)
     _lib.call("sam6d_attention", _p(qkv), _p(qkv, C), _p(qkv, 2 * C), _p(qp), _p(E), _p(hid), Bp, n, n, 3 * C, 3 * C, 3 * C,
               C, n * 3 * C, n * 3 * C, n * 3 * C, n * C, _s())
@@ -555,7 +588,7 @@ def linear_transformer_layer(D, S, L):
     if not (I * J * 128 > 64 * 64 * (I + J)):
         raise RuntimeError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
     kv = _empty((Bp, J, 2 * C), D)
-    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C)
+    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C, w16=L["kv"].w16())
     _lib.call("sam6d_linattn_focus_k", _p(kv), _p(L["scale"]), Bp * J, 2 * C, _s())
     kvT = _empty((Bp, H, 64, 64), D)
     ksum = _empty((Bp, H, 64), D)
@@ -617,7 +650,7 @@ def pe_apply(pts, idx12, W, dst, dst_off, dst_sb):
                   _p(feat), 2 * 128, k * 128, _s())
     m3 = W.pe["mlp3"]
     gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
-         sC=dst_sb, sR=dst_sb)
+         sC=dst_sb, sR=dst_sb, w16=m3.w16())
 
 
 @on_tensor_device
@@ -757,7 +790,7 @@ def _tokens_with_bg(x, lin, bg, extra=None):
     (PEM/model/coarse_point_matching.py:35-38, fine_point_matching.py:47-51)."""
     Bp, N, K = x.shape
     T = _empty((Bp, N + 1, C), x)
-    gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C)
+    gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
     _lib.call("sam6d_put_rows", _p(bg), 0, C, _p(T), (N + 1) * C, C, Bp, 1, C, _s())
     return T
 
@@ -788,7 +821,7 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
     if shared_template and B > 1:
         lin = W.fine["in_proj"]
         D = _empty((Bp, N + 1, C), df)
-        gemm(df, lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B + 1, sA=N * K, sC=(N + 1) * C)  # scene clouds + template slot B
+        gemm(df, lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B + 1, sA=N * K, sC=(N + 1) * C, w16=lin.w16())  # scene clouds + template slot B
         _lib.call("sam6d_put_rows", _p(W.fine["bg"]), 0, C, _p(D), (N + 1) * C, C, B + 1, 1, C, _s())
         grp = pe_group(dp[B:B + 1], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
         return D, grp
@@ -840,6 +873,26 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
     if return_aux:
         return R, t, score, dict(atten=att)
     return R, t, score
+
+
+def _ensure_w16(W):
+    """Cut every Linear of the weight set into its fp16 halves now (first call only), on the caller's stream: the lazily built
+    halves must exist before the pipeline forks its side stream."""
+    if getattr(W, "_w16_done", False):
+        return
+
+    def walk(o):
+        if isinstance(o, Linear):
+            o.w16()
+        elif isinstance(o, dict):
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+    for part in (getattr(W, "coarse", None), getattr(W, "fine", None), getattr(W, "pe", None)):
+        walk(part)
+    W._w16_done = True
 
 
 _SIDE_STREAMS = {}
@@ -957,11 +1010,13 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
     if mb <= 1 or B < 8 * mb or return_aux:
         if _lib.load().sam6d_get_matmul_mode() >= 1:
-            geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
+            geo_packed(W), geo_cheb_packed(W), geo_dcT(W), geo_dcT16(W)  # lazily built weight images: finish them before the streams fork
+            _ensure_w16(W)
         return rest(prepare(0, B, side_key=0), 0, B, 0)
     main = torch.cuda.current_stream()
     if _lib.load().sam6d_get_matmul_mode() >= 1:
-        geo_packed(W), geo_cheb_packed(W), geo_dcT(W)  # lazily built weight images: finish them before the streams fork
+        geo_packed(W), geo_cheb_packed(W), geo_dcT(W), geo_dcT16(W)  # lazily built weight images: finish them before the streams fork
+        _ensure_w16(W)
     per = (B + mb - 1) // mb
     spans = [(i * per, min(B, (i + 1) * per)) for i in range(mb)]
     preps = [prepare(lo, hi) for lo, hi in spans]  # serial, on the caller's stream
