@@ -132,6 +132,13 @@ int sam6d_gemm_ln256(const float* A, const float* W, const float* bias, const fl
  * consts: 2568 floats: b_q | 1/softplus(scale) | b_lin | gamma1 | beta1 | b_expand (512) | b_squeeze | gamma2 | beta2 |
  *   {1/s_q, 1/s_lin, 1/s_exp, 1/(s_sq s_h), s_h, 0, 0, 0} with s_* the pack scales and s_h the scale of the FFN hidden row. */
 int sam6d_pack_panels(const float* W, long ldw, int rows, int k0, int ksteps, float scale, void* dst, void* stream);
+/* Front of RPEMultiHeadAttention.forward (PEM/model/transformer.py:395-405) in one launch: qkv (M,768) = x [Wq;Wk;Wv]^T + b, the
+ * query folded through proj_p per head, qp (M,4,256) = Wp_h^T q_h (see sam6d_attention), and qd (M*4,32) = D_c^T qp_h (see
+ * sam6d_rpe_scores).  wimage (sam6d_rpe_front_image_bytes() bytes) = sam6d_pack_panels of [Wq;Wk;Wv] (768 rows, ksteps 8), then per
+ * head h of proj_p.weight^T (256 rows, k0 = 64 h, ksteps 2), then of D_c^T (32 rows, ksteps 8); inv_* = 1 / the three pack scales. */
+long sam6d_rpe_front_image_bytes(void);
+int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc, float* qkv,
+                    float* qp, float* qd, long M, void* stream);
 long sam6d_token_block_image_bytes(int mode);
 long sam6d_linattn_kv_image_bytes(void);
 int sam6d_linattn_kv_pack(const float* kvT, int B, void* image, float* inv, void* stream);

@@ -610,6 +610,173 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Front of the RPE self-attention layer (RPEMultiHeadAttention.forward, PEM/model/transformer.py:395-405, with proj_p folded into the
+// query as attention.hip / rpe.hip describe): one launch instead of three GEMMs
+//     qkv = x Wqkv^T + b          (M, 768)   written (q | k | v)
+//     qp[n, h, :] = Wp_h^T q_h    (M, 4, 256) the query folded through proj_p, per head (K = 64)
+//     qd[n, h, :] = D_c^T qp_h    (M*4, 32)   Chebyshev coefficients of proj_d applied to the folded query
+// Same register-chained transposed scheme as token_block_kernel: q stays in the accumulators, becomes the B operand of the proj_p
+// fold, whose output becomes the B operand of the D_c product.  Always fp16 x3 (these are the "geometry" folds of matmul mode 2).
+// Image: qkv 24 panels (K = 256) | per head 8 panels of Wp_h^T (K = 64) | D_c^T 1 panel (K = 256).
+#define RF_IMAGE_BYTES (24 * TB_P256 + 32 * TB_P64 + TB_P256)
+struct RfArgs {
+  const float* x;            // (M, 256)
+  const unsigned char* wimg;
+  const float* bias;         // (768)
+  float* qkv;                // (M, 768)
+  float* qp;                 // (M, 1024)
+  float* qd;                 // (M * 4, 32)
+  long M;
+  float inv_qkv, inv_wp, inv_dc;
+};
+
+__global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* pan = lds;  // 2 x TB_PANEL_BYTES
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pan;
+  const long r0 = (long)blockIdx.x * 64 + wave * 16 + fr;
+  const bool valid = r0 < a.M;
+  const long row = valid ? r0 : a.M - 1;
+  constexpr int NPAN = 24 + 4 * 3;
+  // LDS-DMA unit i (32 KiB each): 0..23 the qkv panels (K256); then per head h: two groups of four Wp_h^T panels (K64, 8 KiB each,
+  // contiguous in the image: one barrier per group instead of one per panel), then the D_c^T panel (K256)
+  auto dma = [&](auto IC) {
+    constexpr int I = decltype(IC)::value;
+    if constexpr (I < NPAN) {
+      constexpr size_t off = I < 24 ? (size_t)I * TB_P256
+                                    : (((I - 24) % 3) == 2 ? 24 * (size_t)TB_P256 + 32 * (size_t)TB_P64
+                                                           : 24 * (size_t)TB_P256 + (size_t)(((I - 24) / 3) * 8 + ((I - 24) % 3) * 4) * TB_P64);
+      constexpr int NP = 32 / 4;
+      const unsigned char* src = a.wimg + off;
+      unsigned char* dst = pan + (I & 1) * TB_PANEL_BYTES;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int pc = wave + 4 * k;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                         (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto next_panel = [&](auto IC) -> unsigned {
+    constexpr int I = decltype(IC)::value;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    dma(std::integral_constant<int, I + 1>{});
+    return pan_lds + (I & 1) * TB_PANEL_BYTES;
+  };
+  dma(std::integral_constant<int, 0>{});
+
+  half8 xh[8], xl[8];
+  float sx;
+  {
+    const float* src = a.x + (size_t)row * 256;
+    float4 va[8], vb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
+      vb[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(va[s].x), fabsf(va[s].y)), fmaxf(fabsf(va[s].z), fabsf(va[s].w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(vb[s].x), fabsf(vb[s].y)), fmaxf(fabsf(vb[s].z), fabsf(vb[s].w))));
+    }
+    sx = pow2_scale_for(tok_max(m));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float e[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb[s].x, vb[s].y, vb[s].z, vb[s].w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        _Float16 hi, lo;
+        sam6d_split_f16(e[u] * sx, hi, lo);
+        xh[s][u] = hi;
+        xl[s][u] = lo;
+      }
+    }
+  }
+  // ---- qkv: 24 panels; the q tiles (first 8 panels) are kept for the folds
+  f32x4 qa[16];
+  const float inv0 = a.inv_qkv * (1.0f / sx);
+  float* orow = a.qkv + (size_t)row * 768;
+  tb_static_for<0, 24>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const unsigned p = next_panel(std::integral_constant<int, j>{});
+    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    tb_mma<8>(c0, c1, p, xh, xl, fr, fg, false);
+    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 4 * fg);
+    const float4 b1 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 16 + 4 * fg);
+    c0 = f32x4{c0[0] * inv0 + b0.x, c0[1] * inv0 + b0.y, c0[2] * inv0 + b0.z, c0[3] * inv0 + b0.w};
+    c1 = f32x4{c1[0] * inv0 + b1.x, c1[1] * inv0 + b1.y, c1[2] * inv0 + b1.z, c1[3] * inv0 + b1.w};
+    if (valid) {
+      *reinterpret_cast<float4*>(orow + 32 * j + 4 * fg) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      *reinterpret_cast<float4*>(orow + 32 * j + 16 + 4 * fg) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+    }
+    if constexpr (j < 8) {
+      qa[2 * j] = c0;
+      qa[2 * j + 1] = c1;
+    }
+  });
+  half8 qh[8], ql[8];
+  const float sq = tb_split_rows<16>(qa, qh, ql);
+  // ---- per head: qp_h = Wp_h^T q_h (8 panels, K = 64 = k-steps 2h, 2h+1 of q), then qd_h = D_c^T qp_h (1 panel, K = 256)
+  const float inv1 = a.inv_wp * (1.0f / sq);
+  tb_static_for<0, 4>([&](auto HH) {
+    constexpr int h = decltype(HH)::value;
+    f32x4 pa[16];
+    tb_static_for<0, 2>([&](auto GG) {
+      constexpr int gq = decltype(GG)::value;
+      const unsigned p4 = next_panel(std::integral_constant<int, 24 + 3 * h + gq>{});
+      tb_static_for<0, 4>([&](auto U) {
+        constexpr int j = 4 * gq + decltype(U)::value;
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        tb_mma<2>(c0, c1, p4 + decltype(U)::value * TB_P64, qh + 2 * h, ql + 2 * h, fr, fg, false);
+        pa[2 * j] = f32x4{c0[0] * inv1, c0[1] * inv1, c0[2] * inv1, c0[3] * inv1};
+        pa[2 * j + 1] = f32x4{c1[0] * inv1, c1[1] * inv1, c1[2] * inv1, c1[3] * inv1};
+      });
+    });
+    if (valid) {
+      float* o = a.qp + (size_t)row * 1024 + 256 * h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(o + 16 * i + 4 * fg) = make_float4(pa[i][0], pa[i][1], pa[i][2], pa[i][3]);
+    }
+    half8 ph[8], pl[8];
+    const float sp = tb_split_rows<16>(pa, ph, pl);
+    const unsigned p = next_panel(std::integral_constant<int, 24 + 3 * h + 2>{});
+    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    tb_mma<8>(c0, c1, p, ph, pl, fr, fg, false);
+    if (valid) {
+      const float inv2 = a.inv_dc * (1.0f / sp);
+      float* o = a.qd + ((size_t)row * 4 + h) * 32;
+      *reinterpret_cast<float4*>(o + 4 * fg) = make_float4(c0[0] * inv2, c0[1] * inv2, c0[2] * inv2, c0[3] * inv2);
+      *reinterpret_cast<float4*>(o + 16 + 4 * fg) = make_float4(c1[0] * inv2, c1[1] * inv2, c1[2] * inv2, c1[3] * inv2);
+    }
+  });
+}
+
+extern "C" long sam6d_rpe_front_image_bytes(void) { return RF_IMAGE_BYTES; }
+
+extern "C" int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc,
+                               float* qkv, float* qp, float* qd, long M, void* stream) {
+  SAM6D_REQUIRE(x && wimage && bias_qkv && qkv && qp && qd && M >= 0, "rpe_front: bad arguments");
+  SAM6D_REQUIRE(((((size_t)x) | ((size_t)wimage) | ((size_t)bias_qkv) | ((size_t)qkv) | ((size_t)qp) | ((size_t)qd)) & 15) == 0,
+                "rpe_front: pointers must be 16-byte aligned");
+  if (M == 0) return 0;
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)rpe_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
+    if (e != hipSuccess) {
+      sam6d_set_error("rpe_front: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc};
+  hipLaunchKernelGGL(rpe_front_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("rpe_front");
+}
+
 #define TB_LDS_BYTES(NBUF) ((NBUF) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 
 // Two shapes of the same kernel: 4 waves x 16 tokens with a 2-slot panel ring (77 KB of LDS: two workgroups per CU, which run out
@@ -654,7 +821,7 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   int rc = tb_set_attr();
   if (rc) return rc;
   TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps,
-           sam6d_get_matmul_mode() == 2 ? 1 : 0};
+           sam6d_half_for(1)};
   if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<0, 8, 4>), dim3((unsigned)((M + 127) / 128)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else
@@ -674,7 +841,7 @@ extern "C" int sam6d_linattn_layer(const float* D, const void* wimage, const flo
   const int tiles = (I - row0 + tok - 1) / tok;
   SAM6D_REQUIRE((long)B * tiles < 2147483647L, "linattn_layer: too many tiles");
   TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps,
-           sam6d_get_matmul_mode() == 2 ? 1 : 0};
+           sam6d_half_for(1)};
   if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<1, 8, 4>), dim3((unsigned)(B * tiles)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else

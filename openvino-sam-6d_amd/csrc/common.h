@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #define SAM6D_WAVE 64
 
@@ -184,3 +185,15 @@ static inline bool sam6d_first_use_on_device(unsigned long long* done, int* dev_
   return true;
 }
 #define SAM6D_MAX_DEVICES 64
+
+// matmul mode 2 (fp16 single product) per kernel family: bit 0 generic GEMM, 1 block kernels, 2 cross attention, 3 fine similarity.
+// SAM6D_HALF_MASK (environment, read once; default 15 = all) narrows it -- a bisecting aid, see DESIGN "Mode 2".
+extern "C" int sam6d_get_matmul_mode(void);
+static inline int sam6d_half_for(int family_bit) {
+  static int mask = -1;
+  if (mask < 0) {
+    const char* e = getenv("SAM6D_HALF_MASK");
+    mask = e ? atoi(e) : 15;
+  }
+  return (sam6d_get_matmul_mode() == 2 && ((mask >> family_bit) & 1)) ? 1 : 0;
+}

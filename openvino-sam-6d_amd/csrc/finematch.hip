@@ -467,7 +467,7 @@ extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const 
   const float k1 = log2e / (FM_OPSCALE * FM_OPSCALE * temp), k2 = log2e / temp;
   hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, fh, fl);
   hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * 256)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
-                     sam6d_get_matmul_mode() == 2 ? 1 : 0);
+                     sam6d_half_for(3));
   hipLaunchKernelGGL(fm_bg_kernel, dim3(17, B), dim3(256), 0, s, fh, fl, B, k1, k2, E);
   hipLaunchKernelGGL(fm_merge_sums_kernel, dim3(9, B), dim3(256), 0, s, rowpart, colpart, E, rsum, csum);
   hipLaunchKernelGGL(fm_labels_kernel, dim3(FM_SLABS, B), dim3(256), 0, s, E, rsum, csum, label1, pbest, pidx);

@@ -533,7 +533,7 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
                      sC, sR, divisor, act, b2, ##__VA_ARGS__)
   if (g_matmul_mode >= 1 && K >= 32) {
-    const int half = (g_matmul_mode == 2 && !keep_split) ? 1 : 0;
+    const int half = (sam6d_half_for(0) && !keep_split) ? 1 : 0;
     // 16-byte epilogue accesses need 4-float alignment of every row start and of the per-column vectors
     const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (b2.sC2 & 3) == 0 && (((size_t)C) & 15) == 0 &&
                       (!residual || ((ldr & 3) == 0 && (sR & 3) == 0 && (b2.sR2 & 3) == 0 && (((size_t)residual) & 15) == 0)) &&

@@ -303,7 +303,7 @@ extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void
       return (int)e;
     }
   }
-  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_get_matmul_mode() == 2 ? 1 : 0};
+  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2)};
   hipLaunchKernelGGL(xattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention");
 }

@@ -85,6 +85,8 @@ SIGNATURES = {
     "sam6d_fine_match": [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_cross_attention": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],
     "sam6d_pack_panels": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p],
+    "sam6d_rpe_front_image_bytes": [],
+    "sam6d_rpe_front": [c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_l, c_p],
     "sam6d_token_block_image_bytes": [c_i],
     "sam6d_linattn_kv_image_bytes": [],
     "sam6d_linattn_kv_pack": [c_p, c_i, c_p, c_p, c_p],

@@ -497,18 +497,51 @@ def gemm_b2(A, Wt, out, M, N, K, lda, ldw, ldc, batch, sA, sW, sC, batch2, sA2, 
               sA2, sW2, sC2, _s())
 
 
+def pack_rpe_front(L, dcT):
+    """Panel image of csrc/block.hip's rpe_front_kernel for one self layer: [Wq;Wk;Wv] | per head proj_p^T columns 64h.. | D_c^T."""
+    dev = L["qkv"].w.device
+    nbytes = int(_lib.load().sam6d_rpe_front_image_bytes())
+    assert nbytes == 24 * TB_P256 + 32 * TB_P64 + TB_P256
+    img = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    s_qkv, s_wp, s_dc = _pow2_scale(L["qkv"].w.abs().max()), _pow2_scale(L["wpT"].abs().max()), _pow2_scale(dcT.abs().max())
+    _lib.call("sam6d_pack_panels", _p(L["qkv"].w), C, 3 * C, 0, 8, float(s_qkv), img.data_ptr(), _s())
+    for h in range(H):
+        _lib.call("sam6d_pack_panels", _p(L["wpT"]), C, C, 64 * h, 2, float(s_wp), img.data_ptr() + 24 * TB_P256 + h * 8 * TB_P64, _s())
+    _lib.call("sam6d_pack_panels", _p(dcT), C, 32, 0, 8, float(s_dc), img.data_ptr() + 24 * TB_P256 + 32 * TB_P64, _s())
+    return dict(img=img, inv=(1.0 / s_qkv, 1.0 / s_wp, 1.0 / s_dc))
+
+
 def rpe_self_layer_fused(x, G, L):
     """rpe_self_layer without the embedding tensor (rpe.hip): q.k^T and P.v as batched GEMMs, the geometric term rebuilt from
     the Chebyshev basis inside the score kernel."""
     Bp, n, _ = x.shape
     M = Bp * n
     x2 = x.reshape(M, C)
+    if _fused_block() and os.environ.get("SAM6D_FUSED_FRONT", "1") == "1":
+        # qkv projection, proj_p fold and D_c fold of the query in one launch (block.hip rpe_front_kernel)
+        fr = L.get("front")
+        if fr is None:
+            fr = L["front"] = pack_rpe_front(L, G.dcT)
+        qkv = _empty((M, 3 * C), x)
+        qp = _empty((M, H * C), x)
+        qd = _empty((M * H, 32), x)
+        with _Timed("rpe_front"):
+            _lib.call("sam6d_rpe_front", _p(x2), fr["img"].data_ptr(), _p(L["qkv"].b), fr["inv"][0], fr["inv"][1], fr["inv"][2], _p(qkv),
+                      _p(qp), _p(qd), M, _s())
+        return _rpe_self_tail(x, x2, G, L, qkv, qp, qd)
     qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
     qp = _empty((M, H * C), x)
     # (act 16: the two folds of the geometric embedding into the query stay at fp16 x3 in matmul mode 2 -- "fp32 geometry")
     gemm(qkv, L["wpT"], None, qp, M, C, 64, 3 * C, C, H * C, batch=H, sA=64, sW=64, sC=C, act=16, w16=L.get("wpT16"))
     qd = _empty((M * H, 32), x)
     gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32, act=16, w16=G.dcT16)
+    return _rpe_self_tail(x, x2, G, L, qkv, qp, qd)
+
+
+def _rpe_self_tail(x, x2, G, L, qkv, qp, qd):
+    """q.k^T, geometric scores + softmax, P.v and the layer tail of rpe_self_layer_fused."""
+    Bp, n, _ = x.shape
+    M = Bp * n
     ldp = (n + 3) // 4 * 4
     qk = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
