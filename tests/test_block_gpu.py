@@ -234,3 +234,52 @@ def test_cross_layer_fused_matches_unfused(dev, monkeypatch):
     monkeypatch.setenv("SAM6D_FUSED_BLOCK", "0")
     b = pem.cross_layer(x, mem, L)
     assert float((a - b).abs().max()) < 3e-5
+
+
+# ------------------------------------------------------------------------------------ RPE front and pre-split weight GEMM
+def test_rpe_front_vs_fp64(dev):
+    """sam6d_rpe_front (qkv projection + proj_p fold + D_c fold of the query, block.hip) against float64:
+    qkv = x Wqkv^T + b; qp[n,h,:] = Wp[64h:64h+64, :]^T q_h; qd[n,h,:] = D_c^T qp[n,h,:]   (PEM/model/transformer.py:395-405)."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(77)
+    M = 1000
+    mk = lambda o, i: pem.Linear((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i), (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    qkv = mk(768, 256)
+    Wp = (torch.rand(256, 256, generator=gen) * 2 - 1) / 16
+    dcT = torch.randn(32, 256, generator=gen) * torch.logspace(0, -6, 32).reshape(32, 1)  # decaying coefficient rows, like D_c
+    x = torch.randn(M, 256, generator=gen)
+    d = lambda t: t.double()
+    w_qkv = d(x) @ d(qkv.w).t() + d(qkv.b)
+    q = w_qkv[:, :256]
+    w_qp = torch.stack([q[:, 64 * h:64 * h + 64] @ d(Wp)[64 * h:64 * h + 64, :] for h in range(4)], 1)  # (M, 4, 256)
+    w_qd = w_qp @ d(dcT).t()                                                                            # (M, 4, 32)
+    L = dict(qkv=pem.Linear(qkv.w.to(dev), qkv.b.to(dev)), wpT=Wp.t().contiguous().to(dev))
+    fr = pem.pack_rpe_front(L, dcT.to(dev).contiguous())
+    xd = x.to(dev)
+    o_qkv = torch.full((M, 768), float("nan"), device=dev); o_qp = torch.full((M, 1024), float("nan"), device=dev)
+    o_qd = torch.full((M * 4, 32), float("nan"), device=dev)
+    _lib.call("sam6d_rpe_front", xd.data_ptr(), fr["img"].data_ptr(), L["qkv"].b.data_ptr(), fr["inv"][0], fr["inv"][1], fr["inv"][2],
+              o_qkv.data_ptr(), o_qp.data_ptr(), o_qd.data_ptr(), M, torch.cuda.current_stream().cuda_stream)
+    for got, want, what in ((o_qkv, w_qkv, "qkv"), (o_qp.reshape(M, 4, 256), w_qp, "qp"), (o_qd.reshape(M, 4, 32), w_qd, "qd")):
+        g = got.cpu().double()
+        assert torch.isfinite(g).all(), what
+        err = float((g - want).abs().max()) / float(want.abs().max())
+        assert err < 2e-6, "%s: relative error %.2e" % (what, err)
+
+
+@pytest.mark.parametrize("M,N,K,ws", [(700, 256, 256, 1.0), (5000, 768, 256, 1.0e-3), (300, 32, 256, 40.0), (129, 130, 96, 1.0)])
+def test_gemm_presplit_weights_vs_fp64(dev, M, N, K, ws):
+    """sam6d_gemm_nt_w16 (weights cut into fp16 hi / lo once, with a power-of-two pack scale) against float64 and against the
+    split-on-the-fly kernel."""
+    from sam6d_hip import pem
+    gen = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=gen)
+    lin = pem.Linear(((torch.rand(N, K, generator=gen) * 2 - 1) * ws).to(dev), torch.randn(N, generator=gen).to(dev))
+    want = A.double() @ lin.w.cpu().double().t() + lin.b.cpu().double()
+    Ad = A.to(dev)
+    a = torch.empty(M, N, device=dev); b = torch.empty(M, N, device=dev)
+    pem.gemm(Ad, lin.w, lin.b, a, M, N, K, K, K, N, w16=lin.w16())
+    pem.gemm(Ad, lin.w, lin.b, b, M, N, K, K, K, N)
+    scale = float(want.abs().max())
+    assert float((a.cpu().double() - want).abs().max()) < 4e-6 * scale
+    assert float((a - b).abs().max()) < 4e-6 * scale
