@@ -10,8 +10,9 @@ RCCL inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel (rpe_score_kernel: the geometric self-attention
 scores of the six RPE layers, 21 % of the kernel time, profiles/r02_step3_kernel_stats.csv), timed with HIP events on the launch stream
-inside the timed steps; `roofline_dense_layer` (the fused dense linear-attention layer) and `roofline_fine_match` (similarity + soft
-assignment of the fine stage) the same way; `cpu_baseline` = the CPU oracle (a port of the reference's algorithm,
+inside the timed steps (only that kernel: an event pair is a barrier packet on the stream); `roofline_dense_layer` (the fused dense
+linear-attention layer) and `roofline_fine_match` (similarity + soft assignment of the fine stage) the same way in up to five extra steps
+right behind the timed region; `cpu_baseline` = the CPU oracle (a port of the reference's algorithm,
 oracle/pem_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -141,8 +142,11 @@ def main():
     d = {k: v.to(dev).contiguous() for k, v in inp.items()}
     torch.cuda.synchronize()
 
+    def step_local():
+        return pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+
     def step():
-        R, t, s = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+        R, t, s = step_local()
         return gather_poses(R, t, s, dist) if world > 1 else (R, t, s)
 
     for _ in range(args.warmup):
@@ -151,6 +155,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # HIP events only around the dominant kernel inside the timed region: every event pair is a barrier packet on the stream
+    mode0 = _lib.load().sam6d_get_matmul_mode()
+    pem.PROFILE_NAMES = {"rpe_score_kernel" if (mode0 >= 1 and os.environ.get("SAM6D_FUSED_RPE", "1") == "1") else "geo_embed_kernel"}
     pem.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,7 +167,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, pem.PROFILE = pem.PROFILE, None
+    prof = pem.PROFILE
+    # the two secondary rooflines are timed in a few extra, untimed steps right behind the timed region (same inputs, same launches)
+    pem.PROFILE_NAMES = {"linattn_layer", "fine_match"}
+    pem.PROFILE = {}
+    for _ in range(min(args.steps, 5) if rank == 0 else 0):
+        step_local()
+    torch.cuda.synchronize()
+    prof.update(pem.PROFILE)
+    pem.PROFILE, pem.PROFILE_NAMES = None, None
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -218,7 +233,7 @@ def main():
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": 2 * B * GEO_FLOP_PER_CLOUD / 1e9, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS}
-        # further rooflines (HIP events on the launch stream, inside the timed steps), traffic from the PMC passes under profiles/
+        # further rooflines (HIP events on the launch stream, in the extra steps behind the timed region), traffic from the PMC passes under profiles/
         def _tr(prefix):
             try:
                 k = [k for k in tj["kernels"] if k.startswith(prefix)]
@@ -239,7 +254,7 @@ def main():
             ach = fl / (ms1 * 1e-3) / 1e12
             extra["roofline_dense_layer"] = {
                 "bound": "mfma", "kernel": "token_block_kernel<1> (sam6d_linattn_layer): one dense linear-attention layer over %d clouds, "
-                "%d launches per step" % (2 * B, len(lev) // max(1, args.steps)),
+                "%d launches per step" % (2 * B, len(lev) // max(1, min(args.steps, 5))),
                 "achieved": ach, "peak": PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0), "unit": "TFLOP/s",
                 "frac": ach / (PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0)),
                 "traffic": _tr("token_block_kernel<1>"), "launch_ms": ms1, "launches_timed": len(l_ms),
