@@ -99,6 +99,65 @@ def launch_ranks(n, argv, script=None, extra_env=None, check_devices=True):
     return rc
 
 
+def bench_ism(dev, reps=10):
+    """BASELINE config 3 on one GPU (not the headline metric: reported beside it): 200 proposals x 42 templates through the ISM scoring
+    path -- class-token cosine + avg-5 selection, patch similarity (batched 256 x 256 x 1024 contraction) with appearance score and
+    visible ratio, masked-depth translation + template projection + IoU, final score -- inputs resident in HBM, one host read-back per pass
+    (the count of selected proposals, as in the reference's boolean-mask indexing).  Returns the `ism_config3` object."""
+    import torch
+    from sam6d_hip import ism, synth
+    d = synth.config3_inputs(0)
+    g = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+    def one_pass(timers=None):
+        def mark(name):
+            if timers is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                timers.append((name, e))
+        mark("start")
+        sim = ism.pairwise_similarity(g["q"], g["ref"])
+        sel, obj, sem, best = ism.semantic_select(sim, "avg_5", 0.2)
+        mark("semantic")
+        qa = g["q_appe"][sel]
+        ref_sel = g["r_appe"][obj, best]
+        mark("gather")
+        psim = ism.patch_similarity(qa, ref_sel)
+        mark("patch_similarity")
+        appe, vis = ism.patch_scores(psim, qa)
+        mark("patch_scores")
+        vu, xyxy, tr = ism.project_template_to_image(best, obj, g["poses"], g["pc"], g["masks"][sel], g["depth"], g["K"], g["depth_scale"])
+        iou = ism.compute_iou(xyxy, g["boxes"][sel])
+        fin = ism.final_score(sem, appe, iou, vis)
+        mark("geometric")
+        return fin, len(sel)
+
+    for _ in range(3):
+        fin, ns = one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fin, ns = one_pass()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    tm = []
+    one_pass(tm)
+    torch.cuda.synchronize()
+    stages = {tm[i][0]: tm[i - 1][1].elapsed_time(tm[i][1]) for i in range(1, len(tm))}
+    Nq, Pn, D = g["q_appe"].shape
+    flop = 2.0 * ns * Pn * Pn * D
+    byts = 2.0 * ns * Pn * D * 4 + ns * Pn * Pn * 4  # both descriptor sets read once, similarity written once
+    sim_ms = stages["patch_similarity"]
+    return {"workload": "ISM template scoring, %d proposals x %d templates, %d x %d patch descriptors, %d selected by the 0.2 threshold"
+                        % (Nq, g["ref"].shape[1], Pn, D, ns),
+            "proposals_per_s": Nq / (ms * 1e-3), "ms_per_pass": ms, "stage_ms": stages,
+            "roofline_patch_similarity": {"bound": "hbm", "achieved": byts / 1e9 / (sim_ms * 1e-3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": byts / 1e9 / (sim_ms * 1e-3) / PEAK_HBM_GBS, "traffic": None, "launch_ms": sim_ms,
+                                          "algorithmic_mb_per_launch": byts / 1e6, "algorithmic_gflop_per_launch": flop / 1e9,
+                                          "tflops": flop / 1e12 / (sim_ms * 1e-3)},
+            "finite": bool(torch.isfinite(fin).all())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +165,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-proposals", type=int, default=8, help="proposals in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-ism", action="store_true", help="skip the ISM (config 3) leg reported beside the PEM metric")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -292,6 +352,11 @@ def main():
             "roofline": roofline,
         }
         res.update(extra)
+        if world == 1 and not args.no_ism:
+            try:
+                res["ism_config3"] = bench_ism(dev)
+            except Exception as e:  # the headline line must not depend on the side measurement
+                res["ism_config3"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.cpu_proposals > 0 and world == 1:
             # host cores for the baseline: the GPU box gives a 1-GPU job a share of 16 cores (more threads only
             # oversubscribe the shared host: 256 threads ran the same port 20x slower)

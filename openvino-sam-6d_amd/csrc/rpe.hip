@@ -11,8 +11,8 @@
 //                    \__ qd[n,h,:] (32)                                                    in the softmax: both biases)
 //
 // the d part is a 32-term dot per (pair, head); the a part is a (16 keys x 3) x 32 x 256 contraction per key tile on
-// v_mfma_f32_16x16x32_f16 (fp16 hi/lo split, 3 products), followed by max over k, the 4 head dots on packed-fp32 VALU and a
-// transposing DPP reduction over the 16 channel lanes.  Pairs outside [0, xmax] (the bg token: 2n-1 of n^2) take their
+// v_mfma_f32_16x16x32_f16 (fp16 hi/lo split, 3 products), followed by max over k and a second, small MFMA contraction of the
+// maxima with the folded query (the 4 head dots).  Pairs outside [0, xmax] (the bg token: 2n-1 of n^2) take their
 // bias-free E row from the compact buffer sam6d_geo_outliers filled, old-style (one wave per row).
 // q.k comes in precomputed (one small batched GEMM), softmax happens here, P.V is a batched GEMM afterwards.
 //
@@ -51,17 +51,70 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
 // Persistent workgroups (one per CU) of up to 16 INDEPENDENT waves: a wave owns whole queries (all ceil(n/16) key tiles,
 // the softmax included), so there is no workgroup barrier in the loop and the waves of a CU drift apart -- one wave's loads
 // and VALU phases sit under another's MFMAs.  Only the A_c image (36 KiB) is shared; each wave has a private LDS slice with
-// the folded query [channel][head], qd and its score rows.
-// Per key tile, lane = (kx, kg) with kx = lane & 15 (key of the tile for the A operand, channel of the block for B / D) and
-// kg = lane >> 4:
+// the folded query as MFMA fragments, qd and its score rows.
+// Per key tile, lane = (kx, kg) with kx = lane & 15 and kg = lane >> 4:
 //  * basis: lane (kx, kg) runs ONE fp32 Chebyshev recurrence -- scalar kg of key kx (kg = 0: d_idx, 1..3: a_idx[k]) -- and a
 //    two-stage permlane swap (a 4 x 4 transpose over the 16-lane rows) hands every lane the orders [8 kg, 8 kg + 8) of all
-//    four scalars of its key: exactly the A fragment of v_mfma_f32_16x16x32_f16 (K = 32 = the whole expansion).
-//  * contraction: per 16-channel block 9 MFMAs (3 angular rows x 3 split products), max over the angular rows, 4 head dots
-//    as packed FMAs against the folded query from LDS; D layout: lane = channel kx, rows = keys 4 kg + r.
-//  * a transposing DPP reduction over the 16 channel lanes leaves one (key, head) total per lane.
+//    four scalars of its key: exactly a fragment of v_mfma_f32_16x16x32_f16 (K = 32 = the whole expansion).
+//  * stage 1, per 16-channel block: 9 MFMAs (3 angular rows x 3 split products) with the COEFFICIENTS as the A operand and the
+//    basis as B, so the accumulator comes out transposed -- lane (kx, kg) holds channels 4 kg + r of key kx -- followed by one
+//    v_max3 per register (max over the angular rows).
+//  * stage 2, per pair of blocks: the 8 maxima of a lane are, as they lie, the A fragment (row = key kx, k slot 8 kg + j) of a
+//    second MFMA against the folded query (B: k slot x head) with the channels of a 32-block permuted to match
+//    (slot 8 kg + j <-> channel 16 (j >> 2) + 4 kg + (j & 3)); the maxima are split into fp16 hi / lo (v_cvt_pk_f16_f32 +
+//    v_fma_mix_f32: 2 instructions per value) and contracted with 3 MFMAs.  The 4 head dots and the reduction over the 256
+//    channels -- 256 FMAs, 64 v_max3 and a 60-instruction transposing DPP reduction per tile in the first version of this kernel
+//    -- are 24 MFMAs and 128 conversion instructions; the result (keys 4 kg + r, head kx < 4) needs no cross-lane step at all.
+//    The query side is scaled per query by a power of two (max |qp| -> [2^13, 2^14)), the coefficient image by 1024; the host
+//    checks sum_p |1024 c[ch][p]| < 60 000 (|T_p| <= 1), so no maximum can leave the fp16 range (pem.py geo_cheb_packed).
 // fp32 recurrence: 7e-7 worst case on the projected embedding, below the reference's own fp32 sin/cos argument rounding (3e-6).
-#define RP_QW_FLOATS (256 * 4 + 128)  // per-wave: folded query / 1024 as [channel][head], then qd [head][32]
+#define RP_QF_BYTES 4096                       // folded query as stage-2 B fragments: [G 8][kg 4][head 4][8 halves], hi plane | lo plane
+#define RP_QW_FLOATS (RP_QF_BYTES / 4 + 128)   // + qd [head][32]
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef RP_PRIO
+#define RP_PRIO 1
+#endif
+
+__device__ __forceinline__ unsigned rp_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// f - (float)half, exact: v_fma_mix_f32 reads the low (HI = 0) or high half of h2 as its first operand
+template <int HI>
+__device__ __forceinline__ float rp_sub_half(float f, unsigned h2) {
+  float r;
+  if (HI)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  else
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(f));
+  return r;
+}
+// (a, b) -> packed fp16 hi pair and lo pair, hi + lo = value to 22 bits (same roundings as sam6d_split_f16)
+__device__ __forceinline__ void rp_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = rp_cvt_pk(a, b);
+  lo = rp_cvt_pk(rp_sub_half<0>(a, hi), rp_sub_half<1>(b, hi));
+}
+__device__ __forceinline__ half8 rp_h8(unsigned a, unsigned b, unsigned c, unsigned d) {
+  return __builtin_bit_cast(half8, u32x4{a, b, c, d});
+}
+
+#ifdef RP_STAMP  // diagnostic build only (scratch/): per-wave s_memtime stamps; no output value depends on them
+__device__ unsigned long long rp_stamps[4096 * 12];
+__device__ unsigned long long rp_phase[4096 * 8];
+extern "C" int sam6d_rpe_debug_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rp_stamps), sizeof(unsigned long long) * 4096 * 12);
+}
+extern "C" int sam6d_rpe_debug_phases(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rp_phase), sizeof(unsigned long long) * 4096 * 8);
+}
+#define RP_PH(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tl; tl = now_; }
+#define RP_ST(i) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RP_ST(i)
+#define RP_PH(i)
+#endif
 
 __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict__ idx4, const int* __restrict__ pos,
                                                          const float* __restrict__ rows, const unsigned char* __restrict__ Wc,
@@ -70,34 +123,98 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
                                                          long Q, float xmax, float scale, int mpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* Aw = lds_raw;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int kx = lane & 15, kg = lane >> 4;
   float* qw = reinterpret_cast<float*>(lds_raw + RP_WBYTES) + (size_t)wave * (RP_QW_FLOATS + 4 * mpad);
-  float* qdw = qw + 1024;
+  unsigned char* qf = reinterpret_cast<unsigned char*>(qw);
+  float* qdw = qw + RP_QF_BYTES / 4;
   float* scw = qdw + 128;  // [4][mpad]
+#ifdef RP_STAMP
+  unsigned long long st[12];
+  for (int i = 0; i < 12; ++i) st[i] = 0;
+  int nq = 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;
+  st[8] = __builtin_amdgcn_s_memrealtime();
+  st[10] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |  // HW_ID | XCC_ID << 32
+           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+#endif
+  RP_ST(0);
+  __shared__ int next_query;  // the workgroup's queries (q = blockIdx.x + j * gridDim.x) are handed out in order, one per request
+  if (t == 0) next_query = 0;
   for (int i = t; i < RP_WBYTES / 16; i += blockDim.x) reinterpret_cast<uint4*>(Aw)[i] = reinterpret_cast<const uint4*>(Wc)[i];
   __syncthreads();
+  RP_ST(1);
   const float uscale = 2.0f / xmax;
   const int ntiles = (n + 15) >> 4;
   const unsigned char* wbase = Aw + (size_t)kx * RP_ROW + kg * 16;
-  // query q -> workgroup q % grid, wave (q / grid) % nwaves: the last, partial round is spread over all CUs
-  const long qstride = (long)gridDim.x * nwaves;
-  for (long q = blockIdx.x + (long)gridDim.x * wave; q < Q; q += qstride) {
-    {  // stage the folded query (coefficient image is scaled by 1024, a power of two: undone here, exactly) and qd
-      const float* s = qp + q * 1024 + lane * 4;
-      const float un = 1.0f / 1024.0f;
-      const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 256);
-      const float4 a2 = *reinterpret_cast<const float4*>(s + 512), a3 = *reinterpret_cast<const float4*>(s + 768);
-      float4* d = reinterpret_cast<float4*>(qw) + lane * 4;
-      d[0] = make_float4(a0.x * un, a1.x * un, a2.x * un, a3.x * un);
-      d[1] = make_float4(a0.y * un, a1.y * un, a2.y * un, a3.y * un);
-      d[2] = make_float4(a0.z * un, a1.z * un, a2.z * un, a3.z * un);
-      d[3] = make_float4(a0.w * un, a1.w * un, a2.w * un, a3.w * un);
-      if (lane < 32) reinterpret_cast<float4*>(qdw)[lane] = *reinterpret_cast<const float4*>(qd + q * 128 + lane * 4);
+  const unsigned char* qfl = qf + (kg * 4 + (kx & 3)) * 16;  // this lane's stage-2 B fragment of 32-block G: + 256 G (+ 2048: lo)
+  // Queries are dealt to workgroups round-robin (q % grid) and, inside the workgroup, taken from an LDS counter by whichever wave
+  // is free: the SIMD arbitrates its three waves by age, the oldest runs a query in 90 k cycles while the youngest needs 300 k
+  // beside it (s_memtime stamps, profiles/README.md), so a static deal leaves the old waves idle at the end.
+  const int my_queries = (int)((Q - blockIdx.x + gridDim.x - 1) / gridDim.x);
+  auto take = [&]() {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(&next_query, 1);
+    return __builtin_amdgcn_readfirstlane(j);
+  };
+  // the next query's folded query rows (stage-2 entries e = lane, lane + 64: channels 32 G + 4 kg + {0..3, 16..19} of head e & 3)
+  // and qd are requested before the softmax of the current one
+  float4 pa[2], pb[2], pqd;
+  auto request = [&](long q) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      const float* s = qp + q * 1024 + (e & 3) * 256 + (e >> 4) * 32 + ((e >> 2) & 3) * 4;
+      pa[u] = *reinterpret_cast<const float4*>(s);
+      pb[u] = *reinterpret_cast<const float4*>(s + 16);
     }
+    pqd = *reinterpret_cast<const float4*>(qd + q * 128 + (lane & 31) * 4);
+  };
+  int jq = take();
+  if (jq < my_queries) request(blockIdx.x + (long)jq * gridDim.x);
+  while (jq < my_queries) {
+    const long q = blockIdx.x + (long)jq * gridDim.x;
+#ifdef RP_STAMP
+    tl = __builtin_amdgcn_s_memtime();
+#endif
+    float unscale_a;
+    {  // stage the folded query as stage-2 fragments and qd
+      float4 a[2] = {pa[0], pa[1]}, b[2] = {pb[0], pb[1]};
+      if (lane < 32) reinterpret_cast<float4*>(qdw)[lane] = pqd;
+      float am = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(a[u].x), fabsf(a[u].y)), fmaxf(fabsf(a[u].z), fabsf(a[u].w))));
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(b[u].x), fabsf(b[u].y)), fmaxf(fabsf(b[u].z), fabsf(b[u].w))));
+      }
+      am = wave_max_dpp(am);
+      int k2 = 14 - __builtin_amdgcn_frexp_expf(am);  // am * 2^k2 in [2^13, 2^14)
+      k2 = min(max(k2, -100), 100);
+      k2 = __builtin_amdgcn_readfirstlane(k2);
+      const float beta = ldexpf(1.0f, k2);
+      unscale_a = ldexpf(1.0f, -10 - k2);  // the coefficient image carries 1024
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        rp_split2(a[u].x * beta, a[u].y * beta, h0, l0);
+        rp_split2(a[u].z * beta, a[u].w * beta, h1, l1);
+        rp_split2(b[u].x * beta, b[u].y * beta, h2, l2);
+        rp_split2(b[u].z * beta, b[u].w * beta, h3, l3);
+        *reinterpret_cast<u32x4*>(qf + e * 16) = u32x4{h0, h1, h2, h3};
+        *reinterpret_cast<u32x4*>(qf + 2048 + e * 16) = u32x4{l0, l1, l2, l3};
+      }
+    }
+    // the q.k scores of the query (4 heads x n): in flight under the whole tile loop
+    float sev[4][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sev[h][u] = lane + 64 * u < n ? Se[(q * 4 + h) * ldp + lane + 64 * u] : 0.f;
     const long pbase = q * n;
     float4 v = idx4[pbase + min(kx, n - 1)];
     int ps = pos[pbase + min(kx, n - 1)];
+    RP_PH(0);
     for (int tile = 0; tile < ntiles; ++tile) {
       const int key0 = tile * 16, key = key0 + kx;
       const bool valid = key < n;
@@ -124,6 +241,7 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
           t1 = tp;
           R[p >> 3][p & 7] = tp;
         }
+        RP_PH(5);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           swap32(R[0][j], R[2][j]);
@@ -135,8 +253,10 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
           swap16(R[2][j], R[3][j]);
         }
       }  // R[G][j] = T_{8 kg + j}(scalar G of key kx)
+      RP_PH(6);
 
       // ---- d part: partial dot over this lane's 8 orders for the 4 heads, summed over the 4 lane rows
+      float dtot;
       {
         float sd[4];
 #pragma unroll
@@ -157,131 +277,113 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
         swap32(sd[2], sd[3]);
         float w0 = sd[0] + sd[1], w1 = sd[2] + sd[3];  // lanes 0-31: heads 0 / 2, lanes 32-63: heads 1 / 3
         swap16(w0, w1);
-        const float tot = w0 + w1;  // lane row kg = 2 b5 + b4 holds head 2 b4 + b5
-        const int h = 2 * (kg & 1) + (kg >> 1);
-        if (valid && !listed) scw[h * mpad + key] = tot;
+        dtot = w0 + w1;  // lane row kg = 2 b5 + b4 holds head 2 b4 + b5 of key kx
       }
 
-      // ---- A fragments of the three angular rows (row = key kx, k = 8 kg + j), fp16 hi / lo
+      // ---- basis fragments of the three angular rows (k = 8 kg + j, column = key kx), fp16 hi / lo
       half8 ah[3], al[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k) {
+        unsigned h[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = R[k + 1][j];
-          const _Float16 h = (_Float16)f;
-          ah[k][j] = h;
-          al[k][j] = (_Float16)(f - (float)h);
-        }
-
-      // ---- contraction over the 16 channel blocks; s01 / s23[r] = partial head dots of key row 4 kg + r over this lane's channels
-      f2 s01[4], s23[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s01[r] = f2{0.f, 0.f};
-        s23[r] = f2{0.f, 0.f};
+        for (int j = 0; j < 4; ++j) rp_split2(R[k + 1][2 * j], R[k + 1][2 * j + 1], h[j], l[j]);
+        ah[k] = rp_h8(h[0], h[1], h[2], h[3]);
+        al[k] = rp_h8(l[0], l[1], l[2], l[3]);
       }
-      const float* qbase = qw + kx * 4;
-      // Software pipeline over the channel blocks, written out in issue order and pinned with sched_barrier: the 9 MFMAs of
-      // block cb + 1 alternate with the 12 VALU instructions that consume block cb (a 16x16x32 MFMA holds the vector issue
-      // port for 8 of its 16 cycles; in program order behind a blocked MFMA a wave's own VALU work could not use the rest).
+
+      RP_PH(1);
+      // ---- contraction.  Software pipeline over the channel blocks, written out in issue order and pinned with sched_barrier:
+      // slot s issues the 9 stage-1 MFMAs of block s; between them go the max3 of block s - 1, the fp16 split of block s - 2
+      // and (even s >= 4) the 3 stage-2 MFMAs of the block pair (s - 4, s - 3).
       f32x4 acc[2][3];
       half8 bh[2], bl[2];
-      float4 qv[3];
+      float g[2][4];            // maxima of block cb in g[cb & 1]
+      unsigned gh[2][4], gl[2][4];  // split maxima of the pair G in [G & 1]: even block in [0..1], odd block in [2..3]
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
       auto load_w = [&](int cb) {  // two blocks ahead of their MFMAs: the LDS latency sits under a whole block of MFMAs
         bh[cb & 1] = *reinterpret_cast<const half8*>(wbase + cb * 16 * RP_ROW);
         bl[cb & 1] = *reinterpret_cast<const half8*>(wbase + cb * 16 * RP_ROW + 64);
-        qv[cb % 3] = *reinterpret_cast<const float4*>(qbase + cb * 64);
       };
-      auto mfma1 = [&](int cb, int i) {  // i-th of the 9 MFMAs of block cb: products lo.hi, hi.lo, hi.hi per angular row
+      auto mfma1 = [&](int cb, int i) {  // i-th of the 9 MFMAs of block cb: products hi.lo, lo.hi, hi.hi per angular row
         const int b = cb & 1, k = i % 3, part = i / 3;
-        if (part == 0) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[k], bh[b], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (part == 1) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bl[b], acc[b][k], 0, 0, 0);
-        if (part == 2) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bh[b], acc[b][k], 0, 0, 0);
+        if (part == 0) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[b], al[k], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (part == 1) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[b], ah[k], acc[b][k], 0, 0, 0);
+        if (part == 2) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[b], ah[k], acc[b][k], 0, 0, 0);
       };
-      auto consume = [&](int cb, int r) {  // max over the angular rows, 4 head dots of key row 4 kg + r
+      auto max_row = [&](int cb, int r) {
         const int b = cb & 1;
-        const float g = __builtin_fmaxf(__builtin_fmaxf(acc[b][0][r], acc[b][1][r]), acc[b][2][r]);
-        // four plain FMAs: v_pk_fma_f32 issues at half rate on gfx950 (no gain) and packed fp32 is avoided library-wide
-        s01[r].x = fmaf(g, qv[cb % 3].x, s01[r].x);
-        s01[r].y = fmaf(g, qv[cb % 3].y, s01[r].y);
-        s23[r].x = fmaf(g, qv[cb % 3].z, s23[r].x);
-        s23[r].y = fmaf(g, qv[cb % 3].w, s23[r].y);
+        g[b][r] = __builtin_fmaxf(__builtin_fmaxf(acc[b][0][r], acc[b][1][r]), acc[b][2][r]);
+      };
+      auto split_half = [&](int cb, int half) {  // two of the four maxima of block cb
+        const int G = cb >> 1, o = 2 * (cb & 1) + half;
+        rp_split2(g[cb & 1][2 * half], g[cb & 1][2 * half + 1], gh[G & 1][o], gl[G & 1][o]);
+      };
+      half8 qh, ql;
+      auto load_q = [&](int G) {
+        qh = *reinterpret_cast<const half8*>(qfl + G * 256);
+        ql = *reinterpret_cast<const half8*>(qfl + G * 256 + 2048);
+      };
+      auto mfma2 = [&](int G, int i) {
+        const int p = G & 1;
+        const half8 xh = rp_h8(gh[p][0], gh[p][1], gh[p][2], gh[p][3]);
+        if (i == 0) S = __builtin_amdgcn_mfma_f32_16x16x32_f16(rp_h8(gl[p][0], gl[p][1], gl[p][2], gl[p][3]), qh, S, 0, 0, 0);
+        if (i == 1) S = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, ql, S, 0, 0, 0);
+        if (i == 2) S = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, qh, S, 0, 0, 0);
       };
       load_w(0);
       load_w(1);
+      __builtin_amdgcn_s_setprio(RP_PRIO);  // a wave inside its MFMA loop outranks the waves in their VALU / memory phases
 #pragma unroll
       for (int i = 0; i < 9; ++i) mfma1(0, i);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int cb = 0; cb < 16; ++cb) {
-        if (cb + 1 < 16) {
-          if (cb + 2 < 16) load_w(cb + 2);  // overwrites the weight registers of block cb, whose MFMAs are all issued
+      for (int s = 1; s <= 18; ++s) {
+        if (s + 1 < 16) load_w(s + 1);  // overwrites the fragments of block s - 1, whose MFMAs are all issued
+        const bool st2 = (s & 1) == 0 && s >= 4;
+        if (st2) load_q((s - 4) >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          if (s < 16) mfma1(s, i);
+          if ((i & 1) && s - 1 < 16) max_row(s - 1, i >> 1);          // after MFMAs 1, 3, 5, 7
+          if ((i == 2 || i == 6) && s >= 2 && s - 2 < 16) split_half(s - 2, i >> 2);
+          if (st2 && i >= 6) mfma2((s - 4) >> 1, i - 6);
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            mfma1(cb + 1, i);
-            if (i & 1) consume(cb, i >> 1);  // after MFMAs 1, 3, 5, 7: rows 0..3
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) consume(cb, r);
         }
       }
 
-      // ---- transposing reduction over the 16 channel lanes of each lane row: 16 values -> 1 per lane
-      // value index = h * 4 + r; each stage pairs (2i, 2i+1) and keeps the one selected by a lane bit, so after the four
-      // stages lane bits (b3 b2 b1 b0) hold index b3 + 2 b2 + 4 b1 + 8 b0:  r = b3 + 2 b2,  h = b1 + 2 b0
+      __builtin_amdgcn_s_setprio(0);
+      RP_PH(2);
+      // ---- scores of the tile: the d part from every lane (key kx, head by lane row), then the a part from the lanes kx < 4
+      // (head kx, keys 4 kg + r).  Listed keys (outside the Chebyshev range) get 0: their geometric term was added to the q.k
+      // scores by rpe_listed_kernel.
       {
-        float V[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          V[r] = s01[r].x;
-          V[4 + r] = s01[r].y;
-          V[8 + r] = s23[r].x;
-          V[12 + r] = s23[r].y;
+        const int h = 2 * (kg & 1) + (kg >> 1);
+        scw[h * mpad + key] = listed ? 0.f : dtot;
+        if (kx < 4) {
+          float4* p = reinterpret_cast<float4*>(scw + kx * mpad + key0 + 4 * kg);
+          float4 c = *p;
+          const unsigned m = listed_mask >> (4 * kg);
+          c.x = (m & 1u) ? 0.f : fmaf(S[0], unscale_a, c.x);
+          c.y = (m & 2u) ? 0.f : fmaf(S[1], unscale_a, c.y);
+          c.z = (m & 4u) ? 0.f : fmaf(S[2], unscale_a, c.z);
+          c.w = (m & 8u) ? 0.f : fmaf(S[3], unscale_a, c.w);
+          *p = c;
         }
-        const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-        float W2[8], W3[4], W4[2];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float keep = b3 ? V[2 * i + 1] : V[2 * i], send = b3 ? V[2 * i] : V[2 * i + 1];
-          W2[i] = keep + dpp_mov<0x140>(send);  // row_mirror: lane i <-> 15 - i
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float keep = b2 ? W2[2 * i + 1] : W2[2 * i], send = b2 ? W2[2 * i] : W2[2 * i + 1];
-          W3[i] = keep + dpp_mov<0x141>(send);  // row_half_mirror: lane i <-> 7 - i
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const float keep = b1 ? W3[2 * i + 1] : W3[2 * i], send = b1 ? W3[2 * i] : W3[2 * i + 1];
-          W4[i] = keep + dpp_mov<0x4E>(send);  // quad_perm [2,3,0,1]
-        }
-        const float keep = b0 ? W4[1] : W4[0], send = b0 ? W4[0] : W4[1];
-        const float z = keep + dpp_mov<0xB1>(send);  // quad_perm [1,0,3,2]
-        const int r = (b3 ? 1 : 0) + (b2 ? 2 : 0), h = (b1 ? 1 : 0) + (b0 ? 2 : 0);
-        const int row = 4 * kg + r;
-        if (key0 + row < n && !((listed_mask >> row) & 1u)) scw[h * mpad + key0 + row] += z;
       }
-
-      // listed keys (outside the Chebyshev range): their geometric term was added to the q.k scores by rpe_listed_kernel
-      if (listed && kg == 0) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) scw[h * mpad + key] = 0.f;
-      }
+      RP_PH(3);
     }
     // ---- softmax over the keys (F.softmax: exp(x - max) / sum) of (q.k + geometric term) / 8, probabilities to P[q][h][:]
-#pragma unroll 1
+    jq = take();
+    if (jq < my_queries) request(blockIdx.x + (long)jq * gridDim.x);
+#pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const float* se = Se + (q * 4 + h) * ldp;
       float xv[4];
       float mx = -INFINITY;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = lane + 64 * u;
-        xv[u] = j < n ? (scw[h * mpad + j] + se[j]) * scale : -INFINITY;
+        xv[u] = j < n ? (scw[h * mpad + j] + sev[h][u]) * scale : -INFINITY;
         mx = fmaxf(mx, xv[u]);
       }
       mx = wave_max_dpp(mx);
@@ -300,7 +402,21 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
         if (j < n) pr[j] = xv[u] * inv;
       }
     }
+    RP_PH(4);
+#ifdef RP_STAMP
+    if (nq < 6) st[2 + nq] = __builtin_amdgcn_s_memtime();
+    ++nq;
+#endif
   }
+#ifdef RP_STAMP
+  st[9] = __builtin_amdgcn_s_memrealtime();
+  st[11] = nq;
+  if (lane == 0)
+  {
+    for (int i = 0; i < 12; ++i) rp_stamps[((size_t)blockIdx.x * 12 + wave) * 12 + i] = st[i];
+    for (int i = 0; i < 8; ++i) rp_phase[((size_t)blockIdx.x * 12 + wave) * 8 + i] = ph[i];
+  }
+#endif
 }
 
 // Geometric score term of the listed pairs (an index outside [0, xmax]: the bg token, 2n-1 of n^2 pairs): one wave per pair
@@ -340,7 +456,7 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)wa_cheb | (size_t)qp | (size_t)qd | (size_t)rows) & 15) == 0,
                 "rpe_scores: idx_ws / wa_cheb / qp / qd / rows must be 16-byte aligned");
   if (Q == 0) return 0;
-  const int lds_max = 160 * 1024;
+  const int lds_max = 160 * 1024 - 64;  // dynamic part: the kernel has one static word (its query counter)
   static int n_cu_dev[SAM6D_MAX_DEVICES];
   static unsigned long long rpe_done = 0;
   int dev = 0;

@@ -429,7 +429,16 @@ def geo_cheb_packed(W):
         img = np.concatenate([hi, lo, np.zeros((2, C, 8), np.float16)], axis=2)  # (2, 256, 72 halves = 144 B)
         pk = torch.from_numpy(np.ascontiguousarray(img)).to(W.geo_d.w.device)
         W._geo_cheb = pk
+        # rpe_score_kernel converts the projected angular embedding (x 1024) to fp16 hi / lo for its second contraction: |T_p| <= 1, so
+        # sum_p |1024 c[ch][p]| bounds every value it can meet.  Weights beyond the fp16 range take the materialised-embedding path.
+        W._geo_cheb_fits = bool(np.abs(c[1]).sum(axis=1).max() < 60000.0)
     return pk
+
+
+def fused_rpe_in_range(W):
+    """True when the fused RPE score kernel's fp16 split of the projected embedding cannot overflow for this weight set."""
+    geo_cheb_packed(W)
+    return W._geo_cheb_fits
 
 
 def geo_packed(W):
@@ -459,6 +468,9 @@ def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     PEM/model/transformer.py:306-363; the projections are applied inside sam6d_rpe_scores)."""
     B, n, _ = points_bg.shape
     pairs = B * n * n
+    if not fused_rpe_in_range(W):
+        raise ValueError("geo_context: proj_a of this weight set exceeds the fp16 range of the fused RPE score kernel "
+                         "(sum |Chebyshev coefficients| >= 58.6 per channel); use geo_embedding (SAM6D_FUSED_RPE=0)")
     knn = _empty((B * n * angle_k + 1,), points_bg, torch.int32)  # + the range flag
     idx = _empty((B, n, n, 4), points_bg)
     flag = knn.data_ptr() + 4 * B * n * angle_k
@@ -967,7 +979,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     B = dense_pm.shape[0]
     mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
     fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() >= 1
-    fused = fused and not return_aux
+    fused = fused and not return_aux and fused_rpe_in_range(W)
 
     overlap = cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1")
 

@@ -116,6 +116,36 @@ def config2_inputs(B=32, seed=1, n_dense=2048, n_model=1024):
                 model=model, rand=rand)
 
 
+def config3_inputs(seed=0, Nq=200, Nt=42, D=1024, Pn=256, H=480, W=640):
+    """SURVEY 8d config 3 (ISM template scoring): 200 proposals x 42 templates, 1024-d class tokens, 256 x 1024 patch descriptors with
+    30 % of the patches masked out, box masks on a 480 x 640 depth image, 2048 CAD points, 42 template poses; CPU tensors.  Descriptors
+    of 150 proposals are correlated with the templates so that the 0.2 confidence threshold selects about three quarters of them."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(Nq, D, generator=g)
+    base = torch.randn(D, generator=g)
+    ref = base + 0.8 * torch.randn(1, Nt, D, generator=g)
+    q[:150] = base + 0.5 * ref[0, torch.randint(0, Nt, (150,), generator=g)] + 0.9 * q[:150]
+    q_appe = torch.nn.functional.normalize(torch.randn(Nq, Pn, D, generator=g), dim=-1)
+    r_appe = torch.nn.functional.normalize(torch.randn(1, Nt, Pn, D, generator=g), dim=-1)
+    q_appe = q_appe * (torch.rand(Nq, Pn, 1, generator=g) > 0.3)
+    r_appe = r_appe * (torch.rand(1, Nt, Pn, 1, generator=g) > 0.3)
+    poses = torch.eye(4).repeat(Nt, 1, 1)
+    for i in range(Nt):
+        poses[i, :3, :3] = random_rotation(g)
+    poses[:, :3, 3] = torch.randn(Nt, 3, generator=g) * 0.4
+    pc = (torch.rand(1, 2048, 3, generator=g) - 0.5) * 0.2
+    K = torch.tensor([[572.4114, 0.0, 325.2611], [0.0, 573.57043, 242.04899], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    depth = (800 + 200 * torch.rand(H, W, generator=g)).to(torch.int32)
+    depth[torch.rand(H, W, generator=g) < 0.1] = 0
+    x0 = torch.randint(0, W - 120, (Nq,), generator=g); y0 = torch.randint(0, H - 120, (Nq,), generator=g)
+    bw = torch.randint(40, 120, (Nq,), generator=g); bh = torch.randint(40, 120, (Nq,), generator=g)
+    yy = torch.arange(H).view(1, H, 1); xx = torch.arange(W).view(1, 1, W)
+    masks = ((yy >= y0.view(-1, 1, 1)) & (yy < (y0 + bh).view(-1, 1, 1)) & (xx >= x0.view(-1, 1, 1)) & (xx < (x0 + bw).view(-1, 1, 1))).float()
+    boxes = torch.stack([x0, y0, x0 + bw, y0 + bh], 1)
+    return dict(q=q, ref=ref, q_appe=q_appe, r_appe=r_appe, poses=poses, pc=pc, K=K, depth_scale=torch.tensor(1.0, dtype=torch.float64),
+                depth=depth, masks=masks, boxes=boxes)
+
+
 def random_rotation(g):
     q = torch.randn(4, generator=g)
     q = q / q.norm()

@@ -3,7 +3,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "openvino-sam-6d_amd"))
 import torch
-from sam6d_hip import pem, synth, _lib
+from sam6d_hip import _lib
+if os.environ.get('LIBP'): _lib.LIB_PATH = os.environ['LIBP']
+from sam6d_hip import pem, synth
 dev = torch.device("cuda:0")
 sd = synth.make_pem_weights(1)
 W = pem.PemWeights(sd, dev)

@@ -617,6 +617,48 @@ def test_rpe_self_layer_fused_vs_materialised(dev, W, sd, spread, n):
     _close(got, ora, 1e-4, "fused RPE layer vs oracle")
 
 
+@pytest.mark.parametrize("xs", [1e-4, 1.0, 3e3])
+def test_rpe_fused_query_magnitudes(dev, W, xs):
+    """rpe_score_kernel scales the folded query by a power of two per query before its fp16 split: token features of any magnitude
+    give the same probabilities as the materialised-embedding layer (compared on the attention output before the layer tail's
+    LayerNorm would hide a scale: here on the whole layer with proportionally scaled inputs)."""
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the fused RPE path is the default (fp16x3) mode")
+    gen = torch.Generator().manual_seed(77)
+    B, n = 2, 197
+    pts = (torch.rand(B, n, 3, generator=gen) - 0.5) + torch.tensor([0.3, -0.2, 4.0])
+    pts[:, 0] = 100.0
+    x = torch.randn(B, n, 256, generator=gen)
+    x[0, 5] *= 50.0            # one token far above the others
+    x[1, 7] *= 1e-3            # and one far below
+    x = x * xs
+    L = W.coarse["blocks"][0]["self"]
+    E = pem.geo_embedding(pts.to(dev), W)
+    want = pem.rpe_self_layer(x.to(dev), E, L).cpu()
+    G = pem.geo_context(pts.to(dev), W)
+    got = pem.rpe_self_layer(x.to(dev), G, L).cpu()
+    rel = float((got - want).abs().max() / want.abs().max())
+    print("\nfused RPE layer, feature scale %g: max rel diff %.2e" % (xs, rel))
+    assert torch.isfinite(got).all() and rel < 2e-5
+
+
+def test_rpe_fused_range_guard(dev, sd):
+    """Weights whose projected angular embedding could leave the fp16 range of the score kernel's second contraction are detected on
+    the host (sum of |Chebyshev coefficients| per channel) and keep the materialised-embedding path."""
+    from sam6d_hip import pem
+    W1 = pem.PemWeights(sd, dev)
+    assert pem.fused_rpe_in_range(W1)
+    big = dict(sd)
+    key = [k for k in sd if k.endswith("geometric_structure_embedding.proj_a.weight") or k.endswith("proj_a.weight")][0]
+    big[key] = sd[key] * 4000.0
+    W2 = pem.PemWeights(big, dev)
+    assert not pem.fused_rpe_in_range(W2)
+    pts = torch.rand(1, 32, 3).to(dev)
+    with pytest.raises(ValueError):
+        pem.geo_context(pts, W2)
+
+
 def test_pem_match_fused_vs_materialised(dev, W):
     from sam6d_hip import _lib, pem, synth
     if _lib.load().sam6d_get_matmul_mode() != 1:
