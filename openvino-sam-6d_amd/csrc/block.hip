@@ -33,6 +33,8 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned tb_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // tokens per workgroup = 16 x waves: 64 (4 waves, 2-slot panel ring, two independent workgroups per CU) or 128 (8 waves, 4-slot ring)
@@ -246,11 +248,15 @@ __device__ __forceinline__ float tb_split_rows(const f32x4* v, half8* xh, half8*
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      _Float16 hi, lo;
-      sam6d_split_f16(v[t][r] * sc, hi, lo);
-      xh[t >> 1][4 * (t & 1) + r] = hi;
-      xl[t >> 1][4 * (t & 1) + r] = lo;
+    for (int r = 0; r < 4; r += 2) {
+      unsigned hi, lo;
+      sam6d_split2_f16(v[t][r] * sc, v[t][r + 1] * sc, hi, lo);
+      const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+      const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+      xh[t >> 1][4 * (t & 1) + r] = h2[0];
+      xh[t >> 1][4 * (t & 1) + r + 1] = h2[1];
+      xl[t >> 1][4 * (t & 1) + r] = l2[0];
+      xl[t >> 1][4 * (t & 1) + r + 1] = l2[1];
     }
   return sc;
 }
@@ -425,11 +431,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     for (int s = 0; s < 8; ++s) {
       const float e[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb[s].x, vb[s].y, vb[s].z, vb[s].w};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        _Float16 hi, lo;
-        sam6d_split_f16(e[u] * sx, hi, lo);
-        xh[s][u] = hi;
-        xl[s][u] = lo;
+      for (int u = 0; u < 8; u += 2) {
+        unsigned hi, lo;
+        sam6d_split2_f16(e[u] * sx, e[u + 1] * sx, hi, lo);
+        const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+        const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+        xh[s][u] = h2[0];
+        xh[s][u + 1] = h2[1];
+        xl[s][u] = l2[0];
+        xl[s][u + 1] = l2[1];
       }
     }
   }
@@ -571,13 +581,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
           const float4 be = *reinterpret_cast<const float4*>(cst + TC_BEXP + 128 * c + 32 * u + 16 * w + 4 * fg);
           const float bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = ha[w][r] * inv_e + bb[r];
-            v = (v > 0.f ? v : 0.f) * sh;
-            _Float16 hi, lo;
-            sam6d_split_f16(v, hi, lo);
-            hh[u][4 * w + r] = hi;
-            hl[u][4 * w + r] = lo;
+          for (int r = 0; r < 4; r += 2) {
+            float v0 = ha[w][r] * inv_e + bb[r], v1 = ha[w][r + 1] * inv_e + bb[r + 1];
+            v0 = (v0 > 0.f ? v0 : 0.f) * sh;
+            v1 = (v1 > 0.f ? v1 : 0.f) * sh;
+            unsigned hi, lo;
+            sam6d_split2_f16(v0, v1, hi, lo);
+            const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+            const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+            hh[u][4 * w + r] = h2[0];
+            hh[u][4 * w + r + 1] = h2[1];
+            hl[u][4 * w + r] = l2[0];
+            hl[u][4 * w + r + 1] = l2[1];
           }
         }
       });
@@ -689,11 +704,15 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
     for (int s = 0; s < 8; ++s) {
       const float e[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb[s].x, vb[s].y, vb[s].z, vb[s].w};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        _Float16 hi, lo;
-        sam6d_split_f16(e[u] * sx, hi, lo);
-        xh[s][u] = hi;
-        xl[s][u] = lo;
+      for (int u = 0; u < 8; u += 2) {
+        unsigned hi, lo;
+        sam6d_split2_f16(e[u] * sx, e[u + 1] * sx, hi, lo);
+        const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+        const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+        xh[s][u] = h2[0];
+        xh[s][u + 1] = h2[1];
+        xl[s][u] = l2[0];
+        xl[s][u + 1] = l2[1];
       }
     }
   }

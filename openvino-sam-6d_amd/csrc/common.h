@@ -170,6 +170,18 @@ __device__ __forceinline__ void sam6d_split_f16(float x, _Float16& hi, _Float16&
   lo = (_Float16)(x - (float)hi);
 }
 
+// The same split for a pair, as four instructions: v_cvt_pk_f16_f32 (hi pair, round to nearest even), two v_fma_mix_f32 (x - hi, exact: the
+// fp16 operand is read straight from the packed register) and v_cvt_pk_f16_f32 (lo pair).  The plain C form above costs eight (two
+// conversions, two conversions back, two subtractions, a conversion pair, a pack); every split-precision kernel splits activations between
+// its MFMAs, where vector instructions are what bounds it (profiles/README.md, issue micro-benchmark).  Bit-identical results.
+__device__ __forceinline__ void sam6d_split2_f16(float a, float b, unsigned& hi2, unsigned& lo2) {
+  float la, lb;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi2) : "v"(a), "v"(b));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi2), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi2), "v"(b));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo2) : "v"(la), "v"(lb));
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // One-time per-DEVICE setup (hipFuncSetAttribute, CU count ...): `done` is a bit mask over device ordinals owned by the call site;

@@ -212,11 +212,13 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define H_BK 32
 #define H_LD 40
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
-  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
-  hi = half4{h0, h1, h2, h3};
-  lo = half4{(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
-             (_Float16)(v.w - (float)h3)};
+  unsigned h0, h1, l0, l1;
+  sam6d_split2_f16(v.x, v.y, h0, l0);
+  sam6d_split2_f16(v.z, v.w, h1, l1);
+  hi = __builtin_bit_cast(half4, u32x2{h0, h1});
+  lo = __builtin_bit_cast(half4, u32x2{l0, l1});
 }
 
 // WS: the weight operand arrives pre-split -- Wh / Wl = fp16 hi / lo of W * 2^e, same (N, K) layout and strides as W, cut once at

@@ -159,12 +159,18 @@ __device__ __forceinline__ void pe_split8(const f32x16& acc, int half, const flo
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(&sc[8 * g + 4 * fk]);
     const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[8 * g + 4 * fk]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = fmaf(acc[4 * g + e], s4[e], h4[e]);
-      v = v > 0.f ? v : 0.f;
-      const _Float16 vh = (_Float16)v;
-      hi[4 * g2 + e] = vh;
-      lo[4 * g2 + e] = (_Float16)(v - (float)vh);
+    for (int e = 0; e < 4; e += 2) {
+      float v0 = fmaf(acc[4 * g + e], s4[e], h4[e]), v1 = fmaf(acc[4 * g + e + 1], s4[e + 1], h4[e + 1]);
+      v0 = v0 > 0.f ? v0 : 0.f;
+      v1 = v1 > 0.f ? v1 : 0.f;
+      unsigned ph, pl;
+      sam6d_split2_f16(v0, v1, ph, pl);
+      const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), ph);
+      const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), pl);
+      hi[4 * g2 + e] = h2[0];
+      hi[4 * g2 + e + 1] = h2[1];
+      lo[4 * g2 + e] = l2[0];
+      lo[4 * g2 + e + 1] = l2[1];
     }
   }
 }
