@@ -225,7 +225,7 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // weight-load time (sam6d_split_f16) -- so staging it is a copy: the per-k-step VALU split of the weight tile (half of the
 // kernel's vector work at K = 256) disappears, and so does its range check (the pack scale puts max |W| into [2^13, 2^14)).
 template <int BM, int BN, bool WS>
-__global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
@@ -416,22 +416,25 @@ __global__ __launch_bounds__(256) void gemm_nt_h3_kernel(const float* __restrict
     // Wide epilogue: each wave transposes its 32 x (BN/2) accumulator slab through LDS so that a lane owns 4
     // consecutive columns of one row: residual loads and C stores become 16-byte accesses of full 128/256-byte row
     // segments (the accumulator layout itself gives 4-byte accesses, 4x the instructions and half-used lines).
-    constexpr int WC = BN / 2, SLD = WC + 4, LPR = WC / 4, RPP = 64 / LPR, NP = 32 / RPP;
+    // (at most two 32-column tiles per pass: a 64 x 256 workgroup tile goes through the slab in two passes per row tile)
+    constexpr int EJ = TN > 2 ? 2 : TN, WC = EJ * 32, SLD = WC + 4, LPR = WC / 4, RPP = 64 / LPR, NP = 32 / RPP;
     __syncthreads();  // every wave is done reading operand fragments: the staging buffers can be reused
     float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
     const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
-    const int col = n0 + wn + c4;
-    float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (col < N) {
-      if (bias) bv4 = *reinterpret_cast<const float4*>(bias + col);
-      if (colscale) cs4 = *reinterpret_cast<const float4*>(colscale + col);
-    }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+    for (int jp = 0; jp < TN / EJ; ++jp) {
+      const int col = n0 + wn + jp * WC + c4;
+      float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (col < N) {
+        if (bias) bv4 = *reinterpret_cast<const float4*>(bias + col);
+        if (colscale) cs4 = *reinterpret_cast<const float4*>(colscale + col);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * fk) * SLD + j * 32 + fr] = acc[i][j][r];
+      for (int j = 0; j < EJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((r & 3) + 8 * (r >> 2) + 4 * fk) * SLD + j * 32 + fr] = acc[i][jp * EJ + j][r];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       float4 rv[NP];
@@ -523,7 +526,10 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128) * nz;
   // big tiles when they fill the chip (>= 4 workgroups per CU) and do not mostly pad (M = 197 would waste 42 % of a 2 x 128 split)
   const bool big = blocks128 >= 1024 && (M > 256 || M % 128 == 0);
-  const int tm = cdiv(M, big ? 128 : 64), tn = cdiv(N, big ? 128 : 64);
+  // (64 x 256 tiles -- the whole output row in one workgroup, every A row read and split once -- were measured on the fine in_proj,
+  // M = 131 136, N = K = 256 with pre-split weights: 128 us against 115 us for 128 x 128 tiles; the epilogue keeps its two-pass form)
+  const int bm = big ? 128 : 64, bn = big ? 128 : 64;
+  const int tm = cdiv(M, bm), tn = cdiv(N, bn);
   // all tiles on x (2^31 limit) in the XCD-aware order the kernels decode; groups of 8 row tiles are padded
   const bool fold = nz >= 8;  // batch elements folded into grid.x, one XCD per element (gemm_tile)
   const long tiles = fold ? (long)cdiv(nz, 8) * 8 * tm * tn : (tn <= 8 && tm >= 32) ? (long)cdiv(tm, 8) * 8 * tn : (long)tm * tn;

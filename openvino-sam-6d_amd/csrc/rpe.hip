@@ -390,7 +390,8 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       float sum = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        xv[u] = lane + 64 * u < n ? expf(xv[u] - mx) : 0.f;
+        // (v_exp_f32 on the log2-scaled difference: 1 ulp, arguments <= 0; expf's range reduction is 10 instructions per value)
+        xv[u] = lane + 64 * u < n ? __builtin_amdgcn_exp2f((xv[u] - mx) * 1.4426950408889634f) : 0.f;
         sum += xv[u];
       }
       sum = wave_sum_dpp(sum);
