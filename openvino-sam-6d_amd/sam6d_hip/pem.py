@@ -828,6 +828,14 @@ def sample_pts_feats(pts, feats, npoint):
     _lib.call("sam6d_furthest_point_sampling", _p(pts), Bp, N, npoint, _p(temp), _p(idx), _s())
     sp = _empty((Bp, npoint, 3), pts)
     _lib.call("sam6d_gather_rows", _p(pts), _p(idx), Bp, N, npoint, 3, N * 3, npoint * 3, 0, _p(sp), _s())
+    if isinstance(feats, tuple):  # (scene, template) halves left where the caller holds them: no stacked copy of the features
+        fa, fb = feats
+        Cf, Bh = fa.shape[2], fa.shape[0]
+        sf = _empty((Bp, npoint, Cf), pts)
+        _lib.call("sam6d_gather_rows", _p(fa), _p(idx), Bh, N, npoint, Cf, N * Cf, npoint * Cf, 0, _p(sf), _s())
+        _lib.call("sam6d_gather_rows", _p(fb), _p(idx, Bh * npoint), Bp - Bh, N, npoint, Cf, N * Cf, npoint * Cf, 0,
+                  _p(sf, Bh * npoint * Cf), _s())
+        return sp, sf, idx
     Cf = feats.shape[2]
     sf = _empty((Bp, npoint, Cf), pts)
     _lib.call("sam6d_gather_rows", _p(feats), _p(idx), Bp, N, npoint, Cf, N * Cf, npoint * Cf, 0, _p(sf), _s())
@@ -837,6 +845,15 @@ def sample_pts_feats(pts, feats, npoint):
 def _tokens_with_bg(x, lin, bg, extra=None):
     """cat([bg_token, in_proj(x)], dim=1) for stacked x (B',N,256) -> (B',N+1,256)
     (PEM/model/coarse_point_matching.py:35-38, fine_point_matching.py:47-51)."""
+    if isinstance(x, tuple):  # (scene, template) halves: two batched launches into the one token buffer
+        xa, xb = x
+        Ba, N, K = xa.shape
+        Bp = Ba + xb.shape[0]
+        T = _empty((Bp, N + 1, C), xa)
+        gemm(xa, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Ba, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+        gemm(xb, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C + Ba * (N + 1) * C, batch=Bp - Ba, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+        _lib.call("sam6d_put_rows", _p(bg), 0, C, _p(T), (N + 1) * C, C, Bp, 1, C, _s())
+        return T
     Bp, N, K = x.shape
     T = _empty((Bp, N + 1, C), x)
     gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
@@ -865,12 +882,21 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
     """First half of fine_static: token buffer D with in_proj of both clouds + the template cloud's ball queries (ordinary
     grids that share the chip well).  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
     dense_fo `.repeat`ed per instance, PEM/run_inference_custom_pytorch.py:445-446): its tokens are computed once, in slot B."""
-    Bp, N, K = df.shape
-    B = Bp // 2
+    if isinstance(df, tuple):
+        B, N, K = df[0].shape
+        Bp = 2 * B
+    else:
+        Bp, N, K = df.shape
+        B = Bp // 2
     if shared_template and B > 1:
         lin = W.fine["in_proj"]
-        D = _empty((Bp, N + 1, C), df)
-        gemm(df, lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B + 1, sA=N * K, sC=(N + 1) * C, w16=lin.w16())  # scene clouds + template slot B
+        if isinstance(df, tuple):
+            D = _empty((Bp, N + 1, C), df[0])
+            gemm(df[0], lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+            gemm(df[1], lin.w, lin.b, D, N, C, K, K, K, C, c_off=C + B * (N + 1) * C, batch=1, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+        else:
+            D = _empty((Bp, N + 1, C), df)
+            gemm(df, lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B + 1, sA=N * K, sC=(N + 1) * C, w16=lin.w16())  # scene clouds + template slot B
         _lib.call("sam6d_put_rows", _p(W.fine["bg"]), 0, C, _p(D), (N + 1) * C, C, B + 1, 1, C, _s())
         grp = pe_group(dp[B:B + 1], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
         return D, grp
@@ -1002,7 +1028,9 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         by rest() beside the coarse pose solver.  The micro-batch mode keeps this phase serial."""
         b = hi - lo
         dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
-        df = _cat0(dense_fm[lo:hi], dense_fo[lo:hi])
+        # the features (2 x 67 MB at B = 32) stay where they are: their consumers -- the FPS row gather and the fine in_proj -- read the
+        # two halves with one launch each (a stacked copy cost 0.27 GB of traffic at the head of every step)
+        df = (dense_fm[lo:hi], dense_fo[lo:hi])
         early = None
         if side_key is not None and overlap:
             cur = torch.cuda.current_stream()
@@ -1076,7 +1104,8 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         with torch.cuda.stream(st):
             outs.append(rest(preps[i], lo, hi, ("mb", i, "side")))
         for tns in preps[i][:5]:
-            tns.record_stream(st)
+            for x in (tns if isinstance(tns, tuple) else (tns,)):
+                x.record_stream(st)
     R = _empty((B, 3, 3), dense_pm)
     t = _empty((B, 3), dense_pm)
     sc = _empty((B,), dense_pm)
