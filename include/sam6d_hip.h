@@ -142,6 +142,11 @@ int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, f
 long sam6d_token_block_image_bytes(int mode);
 long sam6d_linattn_kv_image_bytes(void);
 int sam6d_linattn_kv_pack(const float* kvT, int B, void* image, float* inv, void* stream);
+/* The k / v side of LinearAttention (PEM/model/transformer.py:547-572) in one launch: kv (B clouds, J rows of [256 k | 256 v] channels,
+ * row stride ld, cloud stride `stride`, UNfocused keys) -> phi(k), kv^T and the key sums of the 4 heads, and the packed image of kv^T:
+ * the same bits as sam6d_linattn_focus_k + sam6d_linattn_kv + sam6d_linattn_kv_pack (kv itself is left untouched). */
+int sam6d_linattn_kv_image(const float* kv, const float* scale, int B, int J, long ld, long stride, void* image, float* inv,
+                           float* ksum, void* stream);
 int sam6d_token_block(const float* hidden, const float* x, const void* wimage, const float* consts, float* out, long M, float eps,
                       void* stream);
 int sam6d_linattn_layer(const float* D, const void* wimage, const float* consts, const void* kvimage, const float* kvinv,

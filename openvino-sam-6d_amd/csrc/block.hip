@@ -137,6 +137,109 @@ __global__ __launch_bounds__(256) void tb_kv_pack_kernel(const float* __restrict
   }
 }
 
+// ----------------------------------------------------------------------------------------------------- kv side in one launch
+// phi(k) (the focused-ReLU kernel function, linattn.hip focus_row: same operations in the same order), kv^T = sum_j phi(k)_j^T v_j and
+// the key sums of the 4 heads of one cloud, then the packed fp16 image of kv^T with the cloud's power-of-two scale -- what
+// focus_k_kernel + kv_reduce_kernel + tb_kv_pack_kernel did in three launches (15 + 38 + 28 us at 64 clouds x 196 tokens).  One
+// workgroup of 1024 threads per cloud: wave w stages key rows w, w + 16 of every 32-key tile (a wave = one 256-channel row: the focus
+// norms are wave reductions), thread (head h = t >> 8, d = (t >> 2) & 63, c0 = 16 (t & 3)) owns kv^T[h][d][c0 .. c0 + 15] and
+// accumulates over the keys in ascending order, exactly as kv_reduce_kernel does.
+__device__ __forceinline__ float tbk_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(1024) void tb_kv_fused_kernel(const float* __restrict__ kv, const float* __restrict__ scale, int J, long ld,
+                                                           long sb, unsigned char* __restrict__ image, float* __restrict__ inv,
+                                                           float* __restrict__ ksum) {
+  __shared__ float ks[16][256];
+  __shared__ float vs[16][260];
+  __shared__ float red[16];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* kb = kv + (size_t)b * sb;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
+  const float sp[4] = {tbk_softplus(sc.x), tbk_softplus(sc.y), tbk_softplus(sc.z), tbk_softplus(sc.w)};
+  const int h = t >> 8, d = (t >> 2) & 63, c0 = (t & 3) * 16;
+  float acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+  float ksacc = 0.f;  // threads with (t & 255) < 64 accumulate ksum[h][c = t & 63]
+  for (int j0 = 0; j0 < J; j0 += 16) {
+    __syncthreads();
+    {
+      const int j = j0 + wave;  // one key row per wave
+      float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+      if (j < J) {
+        const float4 x = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + lane * 4);
+        vx = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + 256 + lane * 4);
+        float a[4] = {x.x, x.y, x.z, x.w}, c[4];
+        float n1 = 0.f, n3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v = (a[u] > 0.f ? a[u] : 0.f) + 1e-6f;
+          v = v / sp[u];
+          n1 += v * v;
+          c[u] = (v * v) * v;
+          n3 += c[u] * c[u];
+        }
+        n1 = sqrtf(wave_sum_dpp(n1));
+        n3 = sqrtf(wave_sum_dpp(n3));
+        kx = make_float4((c[0] / n3) * n1, (c[1] / n3) * n1, (c[2] / n3) * n1, (c[3] / n3) * n1);
+      }
+      *reinterpret_cast<float4*>(&ks[wave][lane * 4]) = kx;
+      *reinterpret_cast<float4*>(&vs[wave][lane * 4]) = vx;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+      const float vv = vs[jj][h * 64 + d];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] = fmaf(ks[jj][h * 64 + c0 + u], vv, acc[u]);
+      if ((t & 255) < 64) ksacc += ks[jj][h * 64 + (t & 63)];
+    }
+  }
+  if ((t & 255) < 64) ksum[((size_t)b * 4 + h) * 64 + (t & 63)] = ksacc;
+  // the cloud's scale from max |kv^T| (all four heads)
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) m = fmaxf(m, fabsf(acc[u]));
+  m = wave_max_dpp(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float mm = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
+  const float s2 = pow2_scale_for(mm);
+  if (t == 0) inv[b] = 1.0f / s2;
+  // image: head h, row d -> panel 2 h + (d >> 5), row m = d & 31; channel c sits in slot p = 32 (c >> 5) + 8 g + e of the 64-wide K
+  // (tb_slot_channel inverted: g = (c >> 2) & 3, e = 4 ((c >> 4) & 1) + (c & 3))
+  const int mrow = d & 31;
+  _Float16* row = reinterpret_cast<_Float16*>(image + (size_t)b * (8 * TB_P64) + (size_t)(2 * h + (d >> 5)) * TB_P64 +
+                                              (size_t)mrow * TB_ROWB(2));
+#pragma unroll
+  for (int u = 0; u < 16; u += 2) {
+    unsigned hi, lo;
+    sam6d_split2_f16(acc[u] * s2, acc[u + 1] * s2, hi, lo);
+    const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+    const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const int c = c0 + u + w, cc = c & 31;
+      const int pslot = 32 * (c >> 5) + 8 * ((cc >> 2) & 3) + 4 * (cc >> 4) + (cc & 3);
+      row[(((pslot >> 3) ^ (mrow & 15)) << 3) + (pslot & 7)] = h2[w];
+      row[((((64 + pslot) >> 3) ^ (mrow & 15)) << 3) + (pslot & 7)] = l2[w];
+    }
+  }
+}
+
+extern "C" int sam6d_linattn_kv_image(const float* kv, const float* scale, int B, int J, long ld, long stride, void* image, float* inv,
+                                      float* ksum, void* stream) {
+  SAM6D_REQUIRE(kv && scale && image && inv && ksum && B >= 0 && B <= 65535 && J > 0 && ld >= 512 && (ld & 3) == 0 &&
+                    (((size_t)kv | (size_t)scale) & 15) == 0,
+                "linattn_kv_image: bad arguments (kv rows = 256 k | 256 v channels, 16-byte aligned)");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(tb_kv_fused_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
+                     (unsigned char*)image, inv, ksum);
+  SAM6D_LAUNCH_CHECK("linattn_kv_image");
+}
+
 extern "C" int sam6d_linattn_kv_pack(const float* kvT, int B, void* image, float* inv, void* stream) {
   SAM6D_REQUIRE(kvT && image && inv && B >= 0, "linattn_kv_pack: bad arguments");
   if (B == 0) return 0;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sam6d_token_block_image_bytes": [c_i],
     "sam6d_linattn_kv_image_bytes": [],
     "sam6d_linattn_kv_pack": [c_p, c_i, c_p, c_p, c_p],
+    "sam6d_linattn_kv_image": [c_p, c_p, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_p],
     "sam6d_token_block": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     "sam6d_linattn_layer": [c_p] * 7 + [c_i, c_i, c_i, c_f, c_p],
 }

@@ -638,21 +638,22 @@ def linear_transformer_layer(D, S, L):
         raise RuntimeError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
     kv = _empty((Bp, J, 2 * C), D)
     gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C, w16=L["kv"].w16())
-    _lib.call("sam6d_linattn_focus_k", _p(kv), _p(L["scale"]), Bp * J, 2 * C, _s())
-    kvT = _empty((Bp, H, 64, 64), D)
     ksum = _empty((Bp, H, 64), D)
-    _lib.call("sam6d_linattn_kv", _p(kv), _p(kv, C), Bp, J, 2 * C, 2 * C, J * 2 * C, J * 2 * C, _p(kvT), _p(ksum), _s())
     if _fused_block() and "tbd" in L:
         # the whole layer on the dense tokens (rows 1 .. I-1 of every cloud) in one launch; row 0 (the bg slot) is written by the caller
         tb = L["tbd"]
         kvimg = torch.empty(Bp * TB_P64 * 8, dtype=torch.uint8, device=D.device)
         kvinv = _empty((Bp,), D)
-        _lib.call("sam6d_linattn_kv_pack", _p(kvT), Bp, kvimg.data_ptr(), _p(kvinv), _s())
+        # phi(k), kv^T, the key sums and the packed fp16 image of kv^T in one launch (was focus_k + kv + kv_pack)
+        _lib.call("sam6d_linattn_kv_image", _p(kv), _p(L["scale"]), Bp, J, 2 * C, J * 2 * C, kvimg.data_ptr(), _p(kvinv), _p(ksum), _s())
         Dn = _empty((Bp, I, C), D)
         with _Timed("linattn_layer"):
             _lib.call("sam6d_linattn_layer", _p(D), tb["img"].data_ptr(), _p(tb["cst"]), kvimg.data_ptr(), _p(kvinv), _p(ksum), _p(Dn),
                       Bp, I, 1, 1e-5, _s())
         return Dn
+    _lib.call("sam6d_linattn_focus_k", _p(kv), _p(L["scale"]), Bp * J, 2 * C, _s())
+    kvT = _empty((Bp, H, 64, 64), D)
+    _lib.call("sam6d_linattn_kv", _p(kv), _p(kv, C), Bp, J, 2 * C, 2 * C, J * 2 * C, J * 2 * C, _p(kvT), _p(ksum), _s())
     q = linear(D2, L["q"])
     _lib.call("sam6d_linattn_focus_q", _p(q), _p(L["scale"]), _p(ksum), Bp, I, C, _s())
     hid = _empty((rows, C), D)

@@ -76,6 +76,31 @@ def test_token_block_matches_unfused_path(dev, monkeypatch):
     assert float((a - b).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("Bp,J", [(1, 196), (5, 196), (3, 37)])
+def test_linattn_kv_image_equals_three_launches(dev, Bp, J):
+    """sam6d_linattn_kv_image (phi(k) + kv^T + key sums + packed image in one launch) gives the same bits as
+    sam6d_linattn_focus_k + sam6d_linattn_kv + sam6d_linattn_kv_pack, and leaves the kv rows untouched."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(Bp * 100 + J)
+    kv = (torch.randn(Bp, J, 512, generator=gen) * 1.7).to(dev).contiguous()
+    scale = (0.3 * torch.randn(256, generator=gen)).to(dev)
+    nb = int(_lib.load().sam6d_linattn_kv_image_bytes())
+    img1 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv1 = torch.zeros(Bp, device=dev); ks1 = torch.zeros(Bp, 4, 64, device=dev)
+    kv_in = kv.clone()
+    _lib.call("sam6d_linattn_kv_image", pem._p(kv), pem._p(scale), Bp, J, 512, J * 512, img1.data_ptr(), pem._p(inv1), pem._p(ks1), pem._s())
+    assert torch.equal(kv, kv_in)
+    k2 = kv.clone()
+    _lib.call("sam6d_linattn_focus_k", pem._p(k2), pem._p(scale), Bp * J, 512, pem._s())
+    kvT = torch.zeros(Bp, 4, 64, 64, device=dev); ks2 = torch.zeros(Bp, 4, 64, device=dev)
+    _lib.call("sam6d_linattn_kv", pem._p(k2), pem._p(k2, 256), Bp, J, 512, 512, J * 512, J * 512, pem._p(kvT), pem._p(ks2), pem._s())
+    img2 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv2 = torch.zeros(Bp, device=dev)
+    _lib.call("sam6d_linattn_kv_pack", pem._p(kvT), Bp, img2.data_ptr(), pem._p(inv2), pem._s())
+    torch.cuda.synchronize()
+    assert torch.equal(ks1, ks2), "key sums"
+    assert torch.equal(inv1, inv2), "image scale"
+    assert torch.equal(img1, img2), "packed kv^T image: %d bytes differ" % int((img1 != img2).sum())
+
+
 @pytest.mark.parametrize("Bp,I,qs", [(2, 2049, 1.0), (3, 300, 1.0), (1, 130, 1.0), (2, 257, 1.0e4), (2, 257, 1.0e-5)])
 def test_linattn_layer_vs_oracle_math(dev, Bp, I, qs):
     """Whole dense layer on rows 1 .. I-1 against a float64 recompute of LinearAttention + tail (PEM/model/transformer.py:532-622);
