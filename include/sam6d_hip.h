@@ -277,10 +277,14 @@ int sam6d_score_select_hypotheses(const int* sel, const float* Rs, const float* 
 /* Fine-stage similarity + soft assignment as one pipeline (csrc/finematch.hip): compute_feature_similarity
  * (PEM/utils/model_utils.py:131-153: F.normalize both sides, f1 f2^T / temp) followed by the head of compute_fine_Rt (:308-331: the
  * two softmaxes, both arg-max label vectors, the masked assignment's row sums and weighted targets) without materialising the
- * attention matrix more than once.  f (2B, n, 256): out_proj outputs, scene clouds 0..B-1 then template clouds; n = 2049 only
- * (rc < 0 otherwise: use sam6d_gemm_nt + sam6d_soft_assign + sam6d_fine_assign).  pts2 (B, n-1, 3) template points.
- * -> label1, label2 (B, n-1) i32, pred (B, n-1, 3), weight (B, n-1).  ws: sam6d_fine_match_workspace_bytes(B) bytes. */
+ * attention matrix more than once.  f (2B, n, 256): out_proj outputs, scene clouds 0..B-1 then template clouds; n = 2049 (fine_npoint
+ * 2048) or 4097 (BASELINE config 5: 4096-point fine matching; the label and assignment passes then run per 2048-column chunk and two
+ * small kernels merge the chunks in ascending column order) -- rc < 0 otherwise: use sam6d_gemm_nt + sam6d_soft_assign +
+ * sam6d_fine_assign.  pts2 (B, n-1, 3) template points.
+ * -> label1, label2 (B, n-1) i32, pred (B, n-1, 3), weight (B, n-1).  ws: sam6d_fine_match_workspace_bytes_n(B, n) bytes
+ * (sam6d_fine_match_workspace_bytes(B): the n = 2049 size). */
 size_t sam6d_fine_match_workspace_bytes(int B);
+size_t sam6d_fine_match_workspace_bytes_n(int B, int n);
 int sam6d_fine_match(const float* f, int B, int n, float temp, const float* pts2, int* label1, int* label2, float* pred,
                      float* weight, void* ws, size_t ws_bytes, void* stream);
 /* Fine soft-assignment reduction (PEM/utils/model_utils.py:325-331): pred (B,R-1,3), weight (B,R-1). */

@@ -908,7 +908,7 @@ static int tb_shape() {
   static int shape = 0;
   if (!shape) {
     const char* e = getenv("SAM6D_BLOCK_SHAPE");
-    shape = (e && e[0] == '8') ? 8 : 4;
+    shape = (e && e[0] == '8') ? 8 : (e && e[0] == '4' && e[1] == '4') ? 44 : 4;
   }
   return shape;
 }
@@ -929,6 +929,7 @@ static int tb_set_attr() {
     int rc = tb_attr(token_block_kernel<0, 4, 2>, TB_LDS_BYTES(2));
     if (!rc) rc = tb_attr(token_block_kernel<1, 4, 2>, TB_LDS_BYTES(2));
     if (!rc) rc = tb_attr(token_block_kernel<0, 8, 4>, TB_LDS_BYTES(4));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 4, 4>, TB_LDS_BYTES(4));
     if (!rc) rc = tb_attr(token_block_kernel<1, 8, 4>, TB_LDS_BYTES(4));
     if (rc) return rc;
   }
@@ -944,7 +945,9 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   if (rc) return rc;
   TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps,
            sam6d_half_for(1)};
-  if (tb_shape() == 8)
+  if (tb_shape() == 44)
+    hipLaunchKernelGGL((token_block_kernel<0, 4, 4>), dim3((unsigned)((M + 63) / 64)), dim3(256), TB_LDS_BYTES(4), (hipStream_t)stream, a);
+  else if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<0, 8, 4>), dim3((unsigned)((M + 127) / 128)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((token_block_kernel<0, 4, 2>), dim3((unsigned)((M + 63) / 64)), dim3(256), TB_LDS_BYTES(2), (hipStream_t)stream, a);

@@ -26,12 +26,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 #define FM_C 256          // channels
-#define FM_LDE 2052       // row stride of E (floats)
 #define FM_COL0 3         // physical column of logical column 0
-#define FM_NP 2048        // points per cloud (n - 1); the kernels below are specialised for it
-#define FM_SLOTS 33       // partial sums per row / column: 2 per 128-wide tile (16 tiles) + the bg column / row
-#define FM_SLABS 32       // 64-row slabs of the label pass
+#define FM_CHUNK 2048     // columns one label / assignment workgroup covers (32 per lane); np = 2048 (config 2) or 4096 (config 5)
 #define FM_OPSCALE 1024.0f
+// np = points per cloud (n - 1), a multiple of 2048.  Row stride of E: np + 4 floats; partial sums per row / column: 2 per 128-wide tile
+// + the bg column / row; 64-row slabs in the label pass.
+#define FM_LDE(np) ((np) + 4)
+#define FM_SLOTS(np) (2 * ((np) / 128) + 1)
+#define FM_SLABS(np) ((np) / 64)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // F.normalize(dim=-1) (x / max(|x|, 1e-12), model_utils.py:141-142) * 2^10 -> fp16 hi / lo.  One wave per 256-channel row.
@@ -64,20 +66,21 @@ __global__ __launch_bounds__(256) void fm_prep_kernel(const float* __restrict__ 
 #define FM_LD 40  // halves per LDS row (80 B): the ds_read_b128 fragment reads of 16 consecutive rows are conflict-free
 __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B,
                                                      float k1, float k2, float* __restrict__ E, float* __restrict__ rowpart,
-                                                     float* __restrict__ colpart, int half) {
+                                                     float* __restrict__ colpart, int half, int np) {
   __shared__ __attribute__((aligned(16))) _Float16 smem[4 * 128 * FM_LD];  // 40 KB; reused by the epilogue's transpose slabs
   _Float16* Ah = smem;
   _Float16* Al = Ah + 128 * FM_LD;
   _Float16* Bh = Al + 128 * FM_LD;
   _Float16* Bl = Bh + 128 * FM_LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // proposal z's 256 tiles get the workgroup ids congruent to z mod 8: one XCD (one L2) reads that proposal's 2 MB of operands
-  const int per = 256;
+  // proposal z's tiles get the workgroup ids congruent to z mod 8: one XCD (one L2) reads that proposal's operands
+  const int nt = np / 128, per = nt * nt;
   const int g = blockIdx.x / (8 * per), r8 = blockIdx.x % (8 * per);
   const int b = g * 8 + (r8 & 7);
   if (b >= B) return;
-  const int x = r8 >> 3, tm = x & 15, tn = x >> 4;
-  const long n = FM_NP + 1;
+  const int x = r8 >> 3, tm = x % nt, tn = x / nt;
+  const long n = np + 1;
+  const int lde = FM_LDE(np), slots = FM_SLOTS(np);
   const _Float16* a_h = fh + ((long)b * n + 1 + 128 * tm) * FM_C;        // scene cloud b, rows 1 + 128 tm ..
   const _Float16* a_l = fl + ((long)b * n + 1 + 128 * tm) * FM_C;
   const _Float16* w_h = fh + ((long)(B + b) * n + 1 + 128 * tn) * FM_C;  // template cloud B + b
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
     s += xor32_f32(s);
-    if (fk == 0) colpart[((size_t)b * FM_SLOTS + 2 * tm + (wave >> 1)) * FM_NP + mcol0 + wn + 32 * j + fr] = s;
+    if (fk == 0) colpart[((size_t)b * slots + 2 * tm + (wave >> 1)) * np + mcol0 + wn + 32 * j + fr] = s;
   }
   // ---- row partial sums over this wave's 64 columns
 #pragma unroll
@@ -168,14 +171,14 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
       float s = acc[i][0][r] + acc[i][1][r];
       s = row16_sum_dpp(s);
       s += xor16_f32(s);
-      if (fr == 0) rowpart[((size_t)b * FM_NP + nrow0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * FM_SLOTS + 2 * tn + (wave & 1)] = s;
+      if (fr == 0) rowpart[((size_t)b * np + nrow0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * slots + 2 * tn + (wave & 1)] = s;
     }
   // ---- E store: each wave transposes its 32 x 64 slabs through LDS so that a lane owns 4 consecutive columns (16-byte stores)
   constexpr int WC = 64, SLD = WC + 4, LPR = WC / 4, RPP = 64 / LPR, NP = 32 / RPP;
   __syncthreads();
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * SLD);
   const int rr0 = lane / LPR, c4 = (lane % LPR) * 4;
-  float* Eb = E + (size_t)b * (FM_NP + 1) * FM_LDE + FM_COL0;
+  float* Eb = E + (size_t)b * (np + 1) * lde + FM_COL0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
     for (int it = 0; it < NP; ++it) {
       const int rr = it * RPP + rr0;
       const int nn = 1 + nrow0 + wm + 32 * i + rr, mm = 1 + mcol0 + wn + c4;
-      *reinterpret_cast<float4*>(Eb + (size_t)nn * FM_LDE + mm) = *reinterpret_cast<const float4*>(&slab[rr * SLD + c4]);
+      *reinterpret_cast<float4*>(Eb + (size_t)nn * lde + mm) = *reinterpret_cast<const float4*>(&slab[rr * SLD + c4]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -198,10 +201,11 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
 // bg row and bg column: E[0][m] (m = 0 .. 2048) and E[n][0] (n = 1 .. 2048), one wave per dot product over the same scaled
 // hi + lo operands the GEMM multiplies.  grid (17, B): 17 x 256 >= 4097 outputs, 64 per wave.
 __global__ __launch_bounds__(256) void fm_bg_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B, float k1,
-                                                    float k2, float* __restrict__ E) {
+                                                    float k2, float* __restrict__ E, int np) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long n = FM_NP + 1;
-  float* Eb = E + (size_t)b * n * FM_LDE + FM_COL0;
+  const long n = np + 1;
+  const int lde = FM_LDE(np);
+  float* Eb = E + (size_t)b * n * lde + FM_COL0;
   auto rowv = [&](long row, float* x) {
     const half4 h = *reinterpret_cast<const half4*>(fh + row * FM_C + lane * 4);
     const half4 l = *reinterpret_cast<const half4*>(fl + row * FM_C + lane * 4);
@@ -212,20 +216,20 @@ __global__ __launch_bounds__(256) void fm_bg_kernel(const _Float16* __restrict__
   rowv((long)b * n, s0);        // bg token of the scene cloud
   rowv((long)(B + b) * n, t0);  // bg token of the template cloud
   for (int o = (blockIdx.x * 4 + wave) * 64, e = o + 64; o < e; ++o) {
-    if (o >= 2 * FM_NP + 1) break;
+    if (o >= 2 * np + 1) break;
     float y[4];
     float d;
-    if (o <= FM_NP) {  // E[0][m], m = o
+    if (o <= np) {  // E[0][m], m = o
       rowv((long)(B + b) * n + o, y);
       d = fmaf(s0[3], y[3], fmaf(s0[2], y[2], fmaf(s0[1], y[1], s0[0] * y[0])));
     } else {           // E[n][0], n = o - 2048
-      rowv((long)b * n + (o - FM_NP), y);
+      rowv((long)b * n + (o - np), y);
       d = fmaf(t0[3], y[3], fmaf(t0[2], y[2], fmaf(t0[1], y[1], t0[0] * y[0])));
     }
     d = wave_sum_dpp(d);
     if (lane == 0) {
       const float ev = __builtin_amdgcn_exp2f(fmaf(d, k1, -k2));
-      if (o <= FM_NP) Eb[o] = ev; else Eb[(size_t)(o - FM_NP) * FM_LDE] = ev;
+      if (o <= np) Eb[o] = ev; else Eb[(size_t)(o - np) * lde] = ev;
     }
   }
 }
@@ -234,31 +238,32 @@ __global__ __launch_bounds__(256) void fm_bg_kernel(const _Float16* __restrict__
 // grid (9, B): threads 0 .. 2047 of the x range own a row AND a column; entry 2048 -> row 0 / column 0 (read from E).
 __global__ __launch_bounds__(256) void fm_merge_sums_kernel(const float* __restrict__ rowpart, const float* __restrict__ colpart,
                                                             const float* __restrict__ E, float* __restrict__ rsum,
-                                                            float* __restrict__ csum) {
+                                                            float* __restrict__ csum, int np) {
   const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  const float* Eb = E + (size_t)b * (FM_NP + 1) * FM_LDE + FM_COL0;
-  if (i < FM_NP) {
-    const float* rp = rowpart + ((size_t)b * FM_NP + i) * FM_SLOTS;
+  const int lde = FM_LDE(np), slots = FM_SLOTS(np);
+  const float* Eb = E + (size_t)b * (np + 1) * lde + FM_COL0;
+  if (i < np) {
+    const float* rp = rowpart + ((size_t)b * np + i) * slots;
     float s = 0.f;
-    for (int k = 0; k < FM_SLOTS - 1; ++k) s += rp[k];
-    rsum[(size_t)b * (FM_NP + 1) + 1 + i] = s + Eb[(size_t)(1 + i) * FM_LDE];  // + E[n][0]
+    for (int k = 0; k < slots - 1; ++k) s += rp[k];
+    rsum[(size_t)b * (np + 1) + 1 + i] = s + Eb[(size_t)(1 + i) * lde];  // + E[n][0]
     float c = 0.f;
-    for (int k = 0; k < FM_SLOTS - 1; ++k) c += colpart[((size_t)b * FM_SLOTS + k) * FM_NP + i];
-    csum[(size_t)b * (FM_NP + 1) + 1 + i] = c + Eb[1 + i];                    // + E[0][m]
+    for (int k = 0; k < slots - 1; ++k) c += colpart[((size_t)b * slots + k) * np + i];
+    csum[(size_t)b * (np + 1) + 1 + i] = c + Eb[1 + i];                    // + E[0][m]
   }
-  if (blockIdx.x == 8) {  // row 0 / column 0 (bg token): 2049 terms each, summed by the whole workgroup in a fixed order
+  if (blockIdx.x == np / 256) {  // row 0 / column 0 (bg token): np + 1 terms each, summed by the whole workgroup in a fixed order
     __shared__ float red[2][256];
     const int t = threadIdx.x;
     float s = 0.f, c = 0.f;
-    for (int m = t; m <= FM_NP; m += 256) s += Eb[m];
-    for (int nn = t; nn <= FM_NP; nn += 256) c += Eb[(size_t)nn * FM_LDE];
+    for (int m = t; m <= np; m += 256) s += Eb[m];
+    for (int nn = t; nn <= np; nn += 256) c += Eb[(size_t)nn * lde];
     red[0][t] = s;
     red[1][t] = c;
     __syncthreads();
     if (t < 2) {
       float a = 0.f;
       for (int k = 0; k < 256; ++k) a += red[t][k];
-      (t == 0 ? rsum : csum)[(size_t)b * (FM_NP + 1)] = a;
+      (t == 0 ? rsum : csum)[(size_t)b * (np + 1)] = a;
     }
   }
 }
@@ -273,13 +278,17 @@ __device__ __forceinline__ void fm_better(float& bv, int& bi, float v, int i) {
 
 __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict__ E, const float* __restrict__ rsum,
                                                         const float* __restrict__ csum, int* __restrict__ label1,
-                                                        float* __restrict__ pbest, int* __restrict__ pidx) {
-  __shared__ float sv[3][FM_NP];
-  __shared__ int si[3][FM_NP];
-  const int b = blockIdx.y, slab = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* Eb = E + (size_t)b * (FM_NP + 1) * FM_LDE + FM_COL0;
-  const float* rs = rsum + (size_t)b * (FM_NP + 1);
-  const float* cs = csum + (size_t)b * (FM_NP + 1);
+                                                        float* __restrict__ pbest, int* __restrict__ pidx, int np,
+                                                        float* __restrict__ rowbest, int* __restrict__ rowidx) {
+  // blockIdx.z = column chunk (2048 columns): with one chunk the row labels are final here, with more they are candidates per chunk
+  // (rowbest / rowidx [chunk][b][np]) merged by fm_merge_rows_kernel
+  __shared__ float sv[3][FM_CHUNK];
+  __shared__ int si[3][FM_CHUNK];
+  const int b = blockIdx.y, slab = blockIdx.x, chunk = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lde = FM_LDE(np), slabs = FM_SLABS(np), c0 = chunk * FM_CHUNK;
+  const float* Eb = E + (size_t)b * (np + 1) * lde + FM_COL0 + c0;
+  const float* rs = rsum + (size_t)b * (np + 1);
+  const float* cs = csum + (size_t)b * (np + 1) + c0;
   float ics[32], cb[32];
   int ci[32];
 #pragma unroll
@@ -289,16 +298,16 @@ __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int k = 0; k < 32; ++k) { cb[k] = -INFINITY; ci[k] = 0x7fffffff; }
-  const float ics0 = __frcp_rn(cs[0]);
+  const float ics0 = __frcp_rn(csum[(size_t)b * (np + 1)]);
   auto do_row = [&](int nn, bool want_row_label) {
     const float irs = __frcp_rn(rs[nn]);
-    const float* er = Eb + (size_t)nn * FM_LDE;
+    const float* er = Eb + (size_t)nn * lde;
     float4 e[8];
 #pragma unroll
     for (int g = 0; g < 8; ++g) e[g] = *reinterpret_cast<const float4*>(er + 1 + 4 * (lane + 64 * g));
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    if (lane == 0) {  // the bg column: a candidate of the row arg-max only
+    if (lane == 0 && chunk == 0) {  // the bg column: a candidate of the row arg-max only
       const float e0 = er[0];
       bv = (e0 * irs) * (e0 * ics0);
       bi = 0;
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float v = (ev[j] * irs) * (ev[j] * ics[4 * g + j]);
-        if (v > bv) { bv = v; bi = 1 + 4 * (lane + 64 * g) + j; }
+        if (v > bv) { bv = v; bi = c0 + 1 + 4 * (lane + 64 * g) + j; }
         if (v > cb[4 * g + j]) { cb[4 * g + j] = v; ci[4 * g + j] = nn; }
       }
     }
@@ -320,7 +329,13 @@ __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict_
         const int oi = __shfl_xor(bi, o, 64);
         fm_better(bv, bi, ov, oi);
       }
-      if (lane == 0) label1[(size_t)b * FM_NP + nn - 1] = bi;
+      if (lane == 0) {
+        if (gridDim.z == 1) label1[(size_t)b * np + nn - 1] = bi;
+        else {
+          rowbest[((size_t)chunk * gridDim.y + b) * np + nn - 1] = bv;
+          rowidx[((size_t)chunk * gridDim.y + b) * np + nn - 1] = bi;
+        }
+      }
     }
   };
   // (a lane visits its columns in ascending order, g-major, so `v > bv` keeps its first maximum; across lanes fm_better prefers the
@@ -345,23 +360,38 @@ __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict_
       int bi = ci[k];
 #pragma unroll
       for (int w = 0; w < 3; ++w) fm_better(bv, bi, sv[w][m], si[w][m]);
-      pbest[((size_t)b * FM_SLABS + slab) * FM_NP + m] = bv;
-      pidx[((size_t)b * FM_SLABS + slab) * FM_NP + m] = bi;
+      pbest[((size_t)b * slabs + slab) * np + c0 + m] = bv;
+      pidx[((size_t)b * slabs + slab) * np + c0 + m] = bi;
     }
   }
 }
 
 __global__ __launch_bounds__(256) void fm_merge_labels_kernel(const float* __restrict__ pbest, const int* __restrict__ pidx,
-                                                              int* __restrict__ label2) {
+                                                              int* __restrict__ label2, int np) {
   const int b = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= FM_NP) return;
+  if (m >= np) return;
+  const int slabs = FM_SLABS(np);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int s = 0; s < FM_SLABS; ++s) {  // slabs in ascending row order: strict > keeps the first maximum
-    const float v = pbest[((size_t)b * FM_SLABS + s) * FM_NP + m];
-    if (v > bv) { bv = v; bi = pidx[((size_t)b * FM_SLABS + s) * FM_NP + m]; }
+  for (int s = 0; s < slabs; ++s) {  // slabs in ascending row order: strict > keeps the first maximum
+    const float v = pbest[((size_t)b * slabs + s) * np + m];
+    if (v > bv) { bv = v; bi = pidx[((size_t)b * slabs + s) * np + m]; }
   }
-  label2[(size_t)b * FM_NP + m] = (bi == 0x7fffffff) ? 0 : bi;
+  label2[(size_t)b * np + m] = (bi == 0x7fffffff) ? 0 : bi;
+}
+
+// np > 2048: row arg-max over the column chunks (ascending column order: strict > keeps the first maximum)
+__global__ __launch_bounds__(256) void fm_merge_rows_kernel(const float* __restrict__ rowbest, const int* __restrict__ rowidx, int B,
+                                                            int np, int chunks, int* __restrict__ label1) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= np) return;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = 0; c < chunks; ++c) {
+    const float v = rowbest[((size_t)c * B + b) * np + i];
+    if (v > bv) { bv = v; bi = rowidx[((size_t)c * B + b) * np + i]; }
+  }
+  label1[(size_t)b * np + i] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -370,13 +400,16 @@ __global__ __launch_bounds__(256) void fm_merge_labels_kernel(const float* __res
 __global__ __launch_bounds__(256) void fm_assign_kernel(const float* __restrict__ E, const float* __restrict__ rsum,
                                                         const float* __restrict__ csum, const int* __restrict__ label1,
                                                         const int* __restrict__ label2, const float* __restrict__ pts2,
-                                                        float* __restrict__ pred, float* __restrict__ weight) {
-  const int b = blockIdx.y, slab = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* Eb = E + (size_t)b * (FM_NP + 1) * FM_LDE + FM_COL0;
-  const float* rs = rsum + (size_t)b * (FM_NP + 1);
-  const float* cs = csum + (size_t)b * (FM_NP + 1);
-  const int* l2 = label2 + (size_t)b * FM_NP;
-  const float* p2 = pts2 + (size_t)b * FM_NP * 3;
+                                                        float* __restrict__ pred, float* __restrict__ weight, int np,
+                                                        float* __restrict__ part) {
+  // blockIdx.z = column chunk; with more than one chunk the four sums of a row go to part[chunk][b][np][4] (fm_assign_merge_kernel)
+  const int b = blockIdx.y, slab = blockIdx.x, chunk = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lde = FM_LDE(np), c0 = chunk * FM_CHUNK;
+  const float* Eb = E + (size_t)b * (np + 1) * lde + FM_COL0 + c0;
+  const float* rs = rsum + (size_t)b * (np + 1);
+  const float* cs = csum + (size_t)b * (np + 1) + c0;
+  const int* l2 = label2 + (size_t)b * np + c0;
+  const float* p2 = pts2 + ((size_t)b * np + c0) * 3;
   float gc[32], px[32], py[32], pz[32];
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
@@ -397,11 +430,11 @@ __global__ __launch_bounds__(256) void fm_assign_kernel(const float* __restrict_
   }
   for (int k = 0; k < 16; ++k) {
     const int nn = 1 + 64 * slab + wave + 4 * k;
-    const size_t w = (size_t)b * FM_NP + nn - 1;
+    const size_t w = (size_t)b * np + nn - 1;
     float sa = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
     if (label1[w] > 0) {  // (wave-uniform)
       const float irs = __frcp_rn(rs[nn]);
-      const float* er = Eb + (size_t)nn * FM_LDE;
+      const float* er = Eb + (size_t)nn * lde;
       float4 e[8];
 #pragma unroll
       for (int g = 0; g < 8; ++g) e[g] = *reinterpret_cast<const float4*>(er + 1 + 4 * (lane + 64 * g));
@@ -420,58 +453,97 @@ __global__ __launch_bounds__(256) void fm_assign_kernel(const float* __restrict_
       sa = wave_sum(sa); sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
     }
     if (lane == 0) {
-      const float den = sa + 1e-6f;
-      weight[w] = sa;
-      pred[w * 3] = sx / den;
-      pred[w * 3 + 1] = sy / den;
-      pred[w * 3 + 2] = sz / den;
+      if (gridDim.z == 1) {
+        const float den = sa + 1e-6f;
+        weight[w] = sa;
+        pred[w * 3] = sx / den;
+        pred[w * 3 + 1] = sy / den;
+        pred[w * 3 + 2] = sz / den;
+      } else {
+        *reinterpret_cast<float4*>(part + (((size_t)chunk * gridDim.y + b) * np + nn - 1) * 4) = make_float4(sa, sx, sy, sz);
+      }
     }
   }
 }
 
+__global__ __launch_bounds__(256) void fm_assign_merge_kernel(const float* __restrict__ part, int B, int np, int chunks,
+                                                              float* __restrict__ pred, float* __restrict__ weight) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= np) return;
+  float sa = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int c = 0; c < chunks; ++c) {  // chunks in ascending column order
+    const float4 p = *reinterpret_cast<const float4*>(part + (((size_t)c * B + b) * np + i) * 4);
+    sa += p.x; sx += p.y; sy += p.z; sz += p.w;
+  }
+  const size_t w = (size_t)b * np + i;
+  const float den = sa + 1e-6f;
+  weight[w] = sa;
+  pred[w * 3] = sx / den;
+  pred[w * 3 + 1] = sy / den;
+  pred[w * 3 + 2] = sz / den;
+}
+
 static size_t fm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t sam6d_fine_match_workspace_bytes(int B) {
-  const size_t rows = (size_t)2 * B * (FM_NP + 1);
+static size_t fm_workspace_bytes(int B, int np) {
+  const size_t rows = (size_t)2 * B * (np + 1);
+  const int chunks = np / FM_CHUNK;
   size_t s = 0;
-  s += 2 * fm_align(rows * FM_C * 2);                         // fh, fl
-  s += fm_align((size_t)B * (FM_NP + 1) * FM_LDE * 4 + 64);   // E
-  s += 2 * fm_align((size_t)B * FM_NP * FM_SLOTS * 4);        // rowpart, colpart
-  s += 2 * fm_align((size_t)B * (FM_NP + 1) * 4);             // rsum, csum
-  s += 2 * fm_align((size_t)B * FM_SLABS * FM_NP * 4);        // pbest, pidx
+  s += 2 * fm_align(rows * FM_C * 2);                               // fh, fl
+  s += fm_align((size_t)B * (np + 1) * FM_LDE(np) * 4 + 64);        // E
+  s += 2 * fm_align((size_t)B * np * FM_SLOTS(np) * 4);             // rowpart, colpart
+  s += 2 * fm_align((size_t)B * (np + 1) * 4);                      // rsum, csum
+  s += 2 * fm_align((size_t)B * FM_SLABS(np) * np * 4);             // pbest, pidx
+  if (chunks > 1) s += 2 * fm_align((size_t)chunks * B * np * 4) + fm_align((size_t)chunks * B * np * 16);  // row candidates, sums
   return s;
+}
+
+extern "C" size_t sam6d_fine_match_workspace_bytes(int B) { return fm_workspace_bytes(B, 2048); }
+extern "C" size_t sam6d_fine_match_workspace_bytes_n(int B, int n) {
+  return (n > 1 && (n - 1) % FM_CHUNK == 0) ? fm_workspace_bytes(B, n - 1) : 0;
 }
 
 extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const float* pts2, int* label1, int* label2, float* pred,
                                 float* weight, void* ws, size_t ws_bytes, void* stream) {
   SAM6D_REQUIRE(f && pts2 && label1 && label2 && pred && weight && ws, "fine_match: null pointer");
-  SAM6D_REQUIRE(n == FM_NP + 1, "fine_match: specialised for n = %d tokens per cloud (got %d)", FM_NP + 1, n);
+  SAM6D_REQUIRE(n == 2049 || n == 4097, "fine_match: built for n = 2049 or 4097 tokens per cloud (got %d)", n);
   SAM6D_REQUIRE(B >= 0 && B <= 4096 && temp > 0.f, "fine_match: bad sizes");
-  SAM6D_REQUIRE(ws_bytes >= sam6d_fine_match_workspace_bytes(B), "fine_match: workspace too small");
+  const int np = n - 1, chunks = np / FM_CHUNK, lde = FM_LDE(np), slots = FM_SLOTS(np), slabs = FM_SLABS(np), nt = np / 128;
+  SAM6D_REQUIRE(ws_bytes >= fm_workspace_bytes(B, np), "fine_match: workspace too small");
   SAM6D_REQUIRE((((size_t)ws | (size_t)f | (size_t)pts2 | (size_t)label2) & 15) == 0, "fine_match: pointers must be 16-byte aligned");
+  SAM6D_REQUIRE((long)cdiv(B, 8) * 8 * nt * nt < 2147483647L, "fine_match: too many tiles for one launch");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const size_t rows = (size_t)2 * B * n;
   unsigned char* p = (unsigned char*)ws;
   _Float16* fh = (_Float16*)p; p += fm_align(rows * FM_C * 2);
   _Float16* fl = (_Float16*)p; p += fm_align(rows * FM_C * 2);
-  float* E = (float*)p; p += fm_align((size_t)B * n * FM_LDE * 4 + 64);
-  float* rowpart = (float*)p; p += fm_align((size_t)B * FM_NP * FM_SLOTS * 4);
-  float* colpart = (float*)p; p += fm_align((size_t)B * FM_NP * FM_SLOTS * 4);
+  float* E = (float*)p; p += fm_align((size_t)B * n * lde * 4 + 64);
+  float* rowpart = (float*)p; p += fm_align((size_t)B * np * slots * 4);
+  float* colpart = (float*)p; p += fm_align((size_t)B * np * slots * 4);
   float* rsum = (float*)p; p += fm_align((size_t)B * n * 4);
   float* csum = (float*)p; p += fm_align((size_t)B * n * 4);
-  float* pbest = (float*)p; p += fm_align((size_t)B * FM_SLABS * FM_NP * 4);
-  int* pidx = (int*)p;
+  float* pbest = (float*)p; p += fm_align((size_t)B * slabs * np * 4);
+  int* pidx = (int*)p; p += fm_align((size_t)B * slabs * np * 4);
+  float* rowbest = nullptr; int* rowidx = nullptr; float* part = nullptr;
+  if (chunks > 1) {
+    rowbest = (float*)p; p += fm_align((size_t)chunks * B * np * 4);
+    rowidx = (int*)p; p += fm_align((size_t)chunks * B * np * 4);
+    part = (float*)p;
+  }
   // E = exp(att - c) = exp2(acc * k1 - k2): acc carries the operand scale 2^20, att = acc / (2^20 temp), c = 1 / temp
   const float log2e = 1.4426950408889634f;
   const float k1 = log2e / (FM_OPSCALE * FM_OPSCALE * temp), k2 = log2e / temp;
   hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, fh, fl);
-  hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * 256)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
-                     sam6d_half_for(3));
-  hipLaunchKernelGGL(fm_bg_kernel, dim3(17, B), dim3(256), 0, s, fh, fl, B, k1, k2, E);
-  hipLaunchKernelGGL(fm_merge_sums_kernel, dim3(9, B), dim3(256), 0, s, rowpart, colpart, E, rsum, csum);
-  hipLaunchKernelGGL(fm_labels_kernel, dim3(FM_SLABS, B), dim3(256), 0, s, E, rsum, csum, label1, pbest, pidx);
-  hipLaunchKernelGGL(fm_merge_labels_kernel, dim3(FM_NP / 256, B), dim3(256), 0, s, pbest, pidx, label2);
-  hipLaunchKernelGGL(fm_assign_kernel, dim3(FM_SLABS, B), dim3(256), 0, s, E, rsum, csum, label1, label2, pts2, pred, weight);
+  hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * nt * nt)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
+                     sam6d_half_for(3), np);
+  hipLaunchKernelGGL(fm_bg_kernel, dim3(cdiv(2 * np + 1, 256), B), dim3(256), 0, s, fh, fl, B, k1, k2, E, np);
+  hipLaunchKernelGGL(fm_merge_sums_kernel, dim3(np / 256 + 1, B), dim3(256), 0, s, rowpart, colpart, E, rsum, csum, np);
+  hipLaunchKernelGGL(fm_labels_kernel, dim3(slabs, B, chunks), dim3(256), 0, s, E, rsum, csum, label1, pbest, pidx, np, rowbest, rowidx);
+  hipLaunchKernelGGL(fm_merge_labels_kernel, dim3(np / 256, B), dim3(256), 0, s, pbest, pidx, label2, np);
+  if (chunks > 1) hipLaunchKernelGGL(fm_merge_rows_kernel, dim3(np / 256, B), dim3(256), 0, s, rowbest, rowidx, B, np, chunks, label1);
+  hipLaunchKernelGGL(fm_assign_kernel, dim3(slabs, B, chunks), dim3(256), 0, s, E, rsum, csum, label1, label2, pts2, pred, weight, np,
+                     part);
+  if (chunks > 1) hipLaunchKernelGGL(fm_assign_merge_kernel, dim3(np / 256, B), dim3(256), 0, s, part, B, np, chunks, pred, weight);
   SAM6D_LAUNCH_CHECK("fine_match");
 }

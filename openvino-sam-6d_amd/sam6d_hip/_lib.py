@@ -82,6 +82,7 @@ SIGNATURES = {
     "sam6d_choose_points": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
     "sam6d_fine_match_workspace_bytes": [c_i],
+    "sam6d_fine_match_workspace_bytes_n": [c_i, c_i],
     "sam6d_fine_match": [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_cross_attention": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],
     "sam6d_pack_panels": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p],
@@ -115,7 +116,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
-        fn.restype = (c_l if "image_bytes" in name else ctypes.c_size_t) if name.endswith("_bytes") else c_i
+        fn.restype = (c_l if "image_bytes" in name else ctypes.c_size_t) if (name.endswith("_bytes") or name.endswith("_bytes_n")) else c_i
     mode = os.environ.get("SAM6D_MATMUL_MODE")  # 0 = exact fp32 MFMA, 1 = fp16x3 split (library default)
     if mode is not None:
         if lib.sam6d_set_matmul_mode(int(mode)) != 0:

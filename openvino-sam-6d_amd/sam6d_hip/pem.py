@@ -801,7 +801,9 @@ def fine_match(f, B, n, temp, pts2):
     l2 = _empty((B, n - 1), f, torch.int32)
     pred = _empty((B, n - 1, 3), f)
     wgt = _empty((B, n - 1), f)
-    nbytes = int(_lib.load().sam6d_fine_match_workspace_bytes(B))
+    nbytes = int(_lib.load().sam6d_fine_match_workspace_bytes_n(B, n))
+    if nbytes == 0:
+        raise ValueError("fine_match: n = %d tokens per cloud (2049 or 4097 are built)" % n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
     with _Timed("fine_match"):
         _lib.call("sam6d_fine_match", _p(f), B, n, float(temp), _p(pts2), _p(l1), _p(l2), _p(pred), _p(wgt), ws.data_ptr(), nbytes, _s())
@@ -940,7 +942,7 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
                             cfg["pe_nsample2"])
     for blk in W.fine["blocks"]:
         D = sparse_to_dense_transformer(D, E, fps_idx, blk)
-    if not return_aux and N == 2048 and _fused_block():
+    if not return_aux and N in (2048, 4096) and _fused_block():
         # similarity + soft assignment as one pipeline: the (B, 2049, 2049) matrix is written once and read twice (finematch.hip)
         f = linear(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"])
         return compute_fine_Rt_fused(f, B, N + 1, cfg["temp"], dp[:B], dp[B:], model, radius, cfg["dis_thres"])

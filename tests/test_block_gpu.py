@@ -162,13 +162,13 @@ def _fine_match_oracle(F, B, temp, pts2):
 
 
 @pytest.mark.parametrize("kind", ["matched", "flat"])
-def test_fine_match_pipeline_vs_oracle(dev, kind):
+def test_fine_match_pipeline_vs_oracle(dev, kind, n=2049):
     """sam6d_fine_match (finematch.hip) against the oracle.  `matched`: every scene feature is a noisy copy of one template feature (a
     third of them of the bg token), so the arg-max labels are well separated and must be bit-exact; `flat`: unrelated random features
     (a nearly uniform assignment matrix whose arg-max is decided in the last bits): >= 99.5 % of the labels, weights / targets to 1e-5."""
     from sam6d_hip import pem
     gen = torch.Generator().manual_seed(3 if kind == "matched" else 4)
-    B, n = 2, 2049
+    B = 2
     F = torch.randn(2 * B, n, 256, generator=gen)
     if kind == "matched":
         perm = torch.stack([torch.randperm(n, generator=gen) for _ in range(B)])
@@ -191,11 +191,17 @@ def test_fine_match_pipeline_vs_oracle(dev, kind):
         assert float((gw.cpu() - w).abs()[same].max()) < 1e-5
 
 
-def test_fine_match_equals_unfused_path(dev):
-    """same features through the launch-per-op path (l2norm, GEMM, sam6d_soft_assign, sam6d_fine_assign) and the pipeline"""
+def test_fine_match_4097_tokens_vs_oracle(dev):
+    """config 5's fine stage size: labels bit-exact against the oracle on well-separated (matched) features"""
+    test_fine_match_pipeline_vs_oracle(dev, "matched", n=4097)
+
+
+@pytest.mark.parametrize("B,n", [(3, 2049), (2, 4097)])
+def test_fine_match_equals_unfused_path(dev, B, n):
+    """same features through the launch-per-op path (l2norm, GEMM, sam6d_soft_assign, sam6d_fine_assign) and the pipeline; n = 4097 is
+    BASELINE config 5's 4096-point fine stage (label / assignment passes per 2048-column chunk + merges)"""
     from sam6d_hip import pem
     gen = torch.Generator().manual_seed(8)
-    B, n = 3, 2049
     F = torch.randn(2 * B, n, 256, generator=gen)
     perm = torch.randperm(n, generator=gen)
     F[:B] = F[B:, perm] + 0.3 * torch.randn(B, n, 256, generator=gen)
