@@ -256,6 +256,11 @@ int sam6d_l2norm256(const float* x, float* y, long rows, long ldx, long ldy, voi
  * rmax/rsum (B,R), cmax/csum (B,C), label1 (B,R-1) i32, label2 (B,C-1) i32; ws: scratch of >= 32*B*C floats. */
 int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
                       int* label1, int* label2, float* ws, long ws_floats, void* stream);
+/* sam6d_soft_assign + sam6d_coarse_weights in one launch for matrices that fit the 160 KB of LDS of a CU (R * C + 3 R + 3 C floats:
+ * the 197 x 197 coarse attention), one workgroup per proposal; every output has the bits of the two-call form (same per-element
+ * arithmetic, same summation orders: PEM/utils/model_utils.py:229-240).  rc < 0 for larger matrices. */
+int sam6d_coarse_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum, int* label1,
+                             int* label2, float* weights, float* w1, void* stream);
 /* Sampling weights (S[1:,1:] * w1 * w2) ** 1.5 -> (B,(R-1)*(C-1)), w1 (B,R-1) (PEM/utils/model_utils.py:234-238). */
 int sam6d_coarse_weights(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
                          const float* csum, const int* label1, const int* label2, float* weights, float* w1,

@@ -256,6 +256,159 @@ extern "C" int sam6d_coarse_weights(const float* att, int B, int R, int C, const
   SAM6D_LAUNCH_CHECK("coarse_weights");
 }
 
+// The coarse (197 x 197) soft assignment and its weights in ONE launch: one workgroup of 1024 threads per proposal holds the
+// attention matrix in LDS (155 KB) and runs the six passes of sam6d_soft_assign + sam6d_coarse_weights back to back, each with the
+// arithmetic and the summation order of the kernel it replaces (row statistics: sa_row_stats_kernel's per-lane order + wave
+// reductions; column sums: ONE thread per column in row order -- the reference's sequential softmax(dim=1) sum, which the bit-exact
+// hypothesis indices rest on; the arg-max passes only compare per-element values, so a wave per column finds the same first maximum
+// as the sequential scan).  Six launches (216 us, two of them a single thread per column walking global memory) + coarse_weights
+// (62 us) on the critical path of the pose-solver phase.
+__global__ __launch_bounds__(1024) void coarse_assign_kernel(const float* __restrict__ att, int R, int C, float* __restrict__ rmax,
+                                                             float* __restrict__ rsum, float* __restrict__ cmax,
+                                                             float* __restrict__ csum, int* __restrict__ label1,
+                                                             int* __restrict__ label2, float* __restrict__ weights,
+                                                             float* __restrict__ w1) {
+  extern __shared__ __attribute__((aligned(16))) float cas[];
+  float* m = cas;                 // [R][C]
+  float* rm = m + (size_t)R * C;  // [R]
+  float* rs = rm + R;
+  float* cm = rs + R;             // [C]
+  float* cs = cm + C;
+  int* l1 = reinterpret_cast<int*>(cs + C);  // [R] (entry r: label of row r, r >= 1)
+  int* l2 = l1 + R;                          // [C]
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* a = att + (size_t)b * R * C;
+  for (int i = t; i < R * C; i += 1024) m[i] = a[i];
+  __syncthreads();
+  if (wave < 12) {
+    // ---- row statistics (sa_row_stats_kernel, C <= 2304 form): waves 0..11
+    for (int r = wave; r < R; r += 12) {
+      const float* row = m + (size_t)r * C;
+      float mx = -INFINITY, s = 0.f;
+      for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+      mx = wave_max(mx);
+      for (int c = lane; c < C; c += 64) s += expf(row[c] - mx);
+      s = wave_sum(s);
+      if (lane == 0) {
+        rm[r] = mx;
+        rs[r] = s;
+      }
+    }
+  } else {
+    // ---- column statistics (sa_col_stats_part_kernel with one slice), beside the row pass: one thread per column, sequential in row
+    // order
+    for (int c = t - 768; c < C; c += 256) {
+      float mx = -INFINITY;
+      for (int r = 0; r < R; ++r) mx = fmaxf(mx, m[(size_t)r * C + c]);
+      float s = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < R; ++r) s += expf(m[(size_t)r * C + c] - mx);
+      cm[c] = mx;
+      cs[c] = s;
+    }
+  }
+  __syncthreads();
+  // ---- S = softmax(att, 2) * softmax(att, 1), once, in place of the matrix (the three passes below read the same S values the
+  // separate kernels recompute: sa_value is a pure function of the element and its four statistics)
+  for (int i = t; i < R * C; i += 1024) {
+    const int r = i / C, c = i - r * C;
+    m[i] = sa_value(m[i], rm[r], rs[r], cm[c], cs[c]);
+  }
+  __syncthreads();
+  // ---- row labels (sa_row_labels_kernel<false>): first maximum over the columns
+  for (int r = 1 + wave; r < R; r += 16) {
+    const float* row = m + (size_t)r * C;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = row[c];
+      if (v > best) {
+        best = v;
+        bi = c;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) l1[r] = (bi == 0x7fffffff) ? 0 : bi;
+  }
+  // ---- column labels: first maximum over the rows (a wave per column; ties -> the lower row, as the sequential scan keeps)
+  for (int c = 1 + wave; c < C; c += 16) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int r = lane; r < R; r += 64) {
+      const float v = m[(size_t)r * C + c];
+      if (v > best) {
+        best = v;
+        bi = r;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) l2[c] = (bi == 0x7fffffff) ? 0 : bi;
+  }
+  __syncthreads();
+  // ---- outputs: statistics, labels, weights (coarse_weights_kernel)
+  for (int i = t; i < R; i += 1024) {
+    rmax[(size_t)b * R + i] = rm[i];
+    rsum[(size_t)b * R + i] = rs[i];
+    if (i >= 1) {
+      label1[(size_t)b * (R - 1) + i - 1] = l1[i];
+      w1[(size_t)b * (R - 1) + i - 1] = l1[i] > 0 ? 1.f : 0.f;
+    }
+  }
+  for (int i = t; i < C; i += 1024) {
+    cmax[(size_t)b * C + i] = cm[i];
+    csum[(size_t)b * C + i] = cs[i];
+    if (i >= 1) label2[(size_t)b * (C - 1) + i - 1] = l2[i];
+  }
+  const int n1 = R - 1, n2 = C - 1;
+  float* wb = weights + (size_t)b * n1 * n2;
+  for (int e = t; e < n1 * n2; e += 1024) {
+    const int c = e % n2 + 1, r = e / n2 + 1;
+    float v = m[(size_t)r * C + c];
+    const float f1 = l1[r] > 0 ? 1.f : 0.f;
+    const float f2 = l2[c] > 0 ? 1.f : 0.f;
+    v = (v * f1) * f2;
+    wb[e] = powf(v, 1.5f);
+  }
+}
+
+#define CAS_LDS_BYTES(R, C) (((size_t)(R) * (C) + 3 * (size_t)(R) + 3 * (size_t)(C)) * 4)
+extern "C" int sam6d_coarse_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum,
+                                        int* label1, int* label2, float* weights, float* w1, void* stream) {
+  SAM6D_REQUIRE(att && rmax && rsum && cmax && csum && label1 && label2 && weights && w1, "coarse_soft_assign: null pointer");
+  SAM6D_REQUIRE(B >= 0 && R >= 2 && C >= 2 && B <= 65535, "coarse_soft_assign: bad sizes");
+  SAM6D_REQUIRE(CAS_LDS_BYTES(R, C) <= 160 * 1024,
+                "coarse_soft_assign: the %d x %d matrix does not fit the 160 KB of LDS (use sam6d_soft_assign + sam6d_coarse_weights)", R, C);
+  if (B == 0) return 0;
+  static unsigned long long cas_done = 0;
+  if (sam6d_first_use_on_device(&cas_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(coarse_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) {
+      sam6d_set_error("coarse_soft_assign: cannot reserve LDS: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  hipLaunchKernelGGL(coarse_assign_kernel, dim3(B), dim3(1024), CAS_LDS_BYTES(R, C), (hipStream_t)stream, att, R, C, rmax, rsum, cmax,
+                     csum, label1, label2, weights, w1);
+  SAM6D_LAUNCH_CHECK("coarse_soft_assign");
+}
+
 // =========================================================================================================
 // Weighted sampling: cum = cumsum(w) with a DOUBLE accumulator rounded to float per element (torch CPU cumsum,
 // SURVEY 8c n3); cum /= (cum[-1] + 1e-8); idx = first i with cum[i] >= u, 0 if none (model_utils.py:241-243,277-305).

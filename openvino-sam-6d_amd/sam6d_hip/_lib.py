@@ -53,6 +53,7 @@ SIGNATURES = {
     "sam6d_l2norm256": [c_p, c_p, c_l, c_l, c_l, c_p],
     "sam6d_soft_assign": [c_p, c_i, c_i, c_i] + [c_p] * 7 + [c_l, c_p],
     "sam6d_coarse_weights": [c_p, c_i, c_i, c_i] + [c_p] * 9,
+    "sam6d_coarse_soft_assign": [c_p, c_i, c_i, c_i] + [c_p] * 9,
     "sam6d_weighted_sample": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_coarse_hypotheses": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_select_smallest": [c_p, c_i, c_i, c_i, c_p, c_p],

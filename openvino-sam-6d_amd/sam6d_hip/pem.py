@@ -737,12 +737,19 @@ def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_
     rand (B, 3*n_proposal1): the uniforms the reference draws with torch.rand (model_utils.py:292)."""
     B, R, Cn = att.shape
     N1, N2 = R - 1, Cn - 1
-    st = soft_assign(att)
     L = N1 * N2
     w = _empty((B, L), att)
     w1 = _empty((B, N1), att)
-    _lib.call("sam6d_coarse_weights", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
-              _p(st["l1"]), _p(st["l2"]), _p(w), _p(w1), _s())
+    if (R * Cn + 3 * R + 3 * Cn) * 4 <= 160 * 1024:
+        # the whole soft assignment of a proposal from LDS, one launch (bit-identical to the two calls below)
+        st = dict(rmax=_empty((B, R), att), rsum=_empty((B, R), att), cmax=_empty((B, Cn), att), csum=_empty((B, Cn), att),
+                  l1=_empty((B, R - 1), att, torch.int32), l2=_empty((B, Cn - 1), att, torch.int32))
+        _lib.call("sam6d_coarse_soft_assign", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
+                  _p(st["l1"]), _p(st["l2"]), _p(w), _p(w1), _s())
+    else:
+        st = soft_assign(att)
+        _lib.call("sam6d_coarse_weights", _p(att), B, R, Cn, _p(st["rmax"]), _p(st["rsum"]), _p(st["cmax"]), _p(st["csum"]),
+                  _p(st["l1"]), _p(st["l2"]), _p(w), _p(w1), _s())
     ns = 3 * n_proposal1
     cum = _empty((B, L), att)
     idx = _empty((B, ns), att, torch.int32)

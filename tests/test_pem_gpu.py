@@ -760,3 +760,34 @@ def test_template_cloud_fps_210k(dev):
     assert torch.equal(idx.cpu(), want)
     assert torch.equal(sp.cpu(), torch.gather(pts, 1, want.long().unsqueeze(2).expand(1, 2048, 3)))
     assert torch.equal(sf.cpu(), torch.gather(feats, 1, want.long().unsqueeze(2).expand(1, 2048, 8)))
+
+
+@pytest.mark.parametrize("B,R,C,peaky", [(3, 197, 197, False), (2, 197, 197, True), (2, 50, 120, False), (1, 2, 2, False)])
+def test_coarse_soft_assign_one_launch_is_bit_identical(dev, B, R, C, peaky):
+    """sam6d_coarse_soft_assign (matrix in LDS, one workgroup per proposal) against sam6d_soft_assign + sam6d_coarse_weights: every
+    statistic, label and weight bit for bit (the sampled hypothesis indices downstream depend on the exact weights)."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(B * 1000 + R + C + int(peaky))
+    att = torch.randn(B, R, C, generator=gen) * (0.2 if not peaky else 1.0)
+    if peaky:
+        for b in range(B):
+            perm = torch.randperm(C - 1, generator=gen)[: R - 1] + 1
+            att[b, torch.arange(1, R), perm[: R - 1]] += 12.0
+            att[b, 1:40, 0] += 15.0  # some rows prefer the bg column
+    att = att.to(dev).contiguous()
+    st = pem.soft_assign(att)
+    w = torch.zeros(B, (R - 1) * (C - 1), device=dev); w1 = torch.zeros(B, R - 1, device=dev)
+    _lib.call("sam6d_coarse_weights", pem._p(att), B, R, C, pem._p(st["rmax"]), pem._p(st["rsum"]), pem._p(st["cmax"]), pem._p(st["csum"]),
+              pem._p(st["l1"]), pem._p(st["l2"]), pem._p(w), pem._p(w1), pem._s())
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+    o = dict(rmax=z(B, R), rsum=z(B, R), cmax=z(B, C), csum=z(B, C), l1=z(B, R - 1, dt=torch.int32), l2=z(B, C - 1, dt=torch.int32))
+    w2 = z(B, (R - 1) * (C - 1)); w12 = z(B, R - 1)
+    _lib.call("sam6d_coarse_soft_assign", pem._p(att), B, R, C, pem._p(o["rmax"]), pem._p(o["rsum"]), pem._p(o["cmax"]), pem._p(o["csum"]),
+              pem._p(o["l1"]), pem._p(o["l2"]), pem._p(w2), pem._p(w12), pem._s())
+    torch.cuda.synchronize()
+    for k in ("rmax", "rsum", "cmax", "csum", "l1", "l2"):
+        assert torch.equal(st[k], o[k]), k
+    assert torch.equal(w, w2), "weights: %d differ" % int((w != w2).sum())
+    assert torch.equal(w1, w12)
+    if peaky:
+        assert int((o["l1"] > 0).sum()) > 0 and int((o["l1"] == 0).sum()) > 0
