@@ -182,9 +182,11 @@ def test_error_contract(dev, ext):
         ext.three_nn(x, x)
 
 
-@pytest.mark.parametrize("B,N,M,r1,ns1,r2,ns2", [(2, 2048, 2048, 0.1, 32, 0.2, 64), (1, 5000, 300, 0.05, 16, 0.4, 64), (3, 100, 100, 0.3, 8, 0.01, 4)])
+@pytest.mark.parametrize("B,N,M,r1,ns1,r2,ns2", [(2, 2048, 2048, 0.1, 32, 0.2, 64), (1, 5000, 300, 0.05, 16, 0.4, 64), (3, 100, 100, 0.3, 8, 0.01, 4),
+                                                   (3, 3000, 1500, 0.3, 8, 0.02, 5), (5, 1111, 1111, 0.12, 32, 0.5, 64), (32, 2048, 2048, 0.1, 32, 0.2, 64)])
 def test_ball_query2_equals_two_single_queries(dev, B, N, M, r1, ns1, r2, ns2):
-    """The two-radius pass used by the positional encoding returns exactly what two single-radius calls return."""
+    """The two-radius pass used by the positional encoding returns exactly what two single-radius calls return (large query sets go
+    through the one-lane-per-query kernel, small ones through the wave-per-query kernel)."""
     from sam6d_hip import _lib
     g = torch.Generator().manual_seed(N + M)
     xyz = torch.rand(B, N, 3, generator=g).to(dev)
