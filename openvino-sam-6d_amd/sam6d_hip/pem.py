@@ -890,7 +890,7 @@ def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=Fal
 
 def fine_static_a(dp, df, W, cfg, shared_template=False):
     """First half of fine_static: token buffer D with in_proj of both clouds + the template cloud's ball queries (ordinary
-    grids that share the chip well).  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
+    grids that share the chip well).  df: stacked (2B,N,256) or the (scene, template) pair.  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
     dense_fo `.repeat`ed per instance, PEM/run_inference_custom_pytorch.py:445-446): its tokens are computed once, in slot B."""
     if isinstance(df, tuple):
         B, N, K = df[0].shape
@@ -937,7 +937,8 @@ def fine_static(dp, df, W, cfg, shared_template=False):
 
 
 def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None, shared_template=False):
-    """dp (2B,N,3), df (2B,N,256) stacked [scene; template]  (PEM/model/fine_point_matching.py:42-79, eval).
+    """dp (2B,N,3) stacked [scene; template], df the dense features: (2B,N,256) stacked the same way, or the pair (scene (B,N,256),
+    template (B,N,256)) left where the caller holds them  (PEM/model/fine_point_matching.py:42-79, eval).
     D: the result of fine_static() when the caller has already produced it."""
     Bp, N, _ = dp.shape
     B = Bp // 2
