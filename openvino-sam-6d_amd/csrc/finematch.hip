@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// bg row and bg column: E[0][m] (m = 0 .. 2048) and E[n][0] (n = 1 .. 2048), one wave per dot product over the same scaled
-// hi + lo operands the GEMM multiplies.  grid (17, B): 17 x 256 >= 4097 outputs, 64 per wave.
+// bg row and bg column: E[0][m] (m = 0 .. np) and E[n][0] (n = 1 .. np), one wave per dot product over the same scaled
+// hi + lo operands the GEMM multiplies; 8 outputs per wave (64 per wave left each wave a chain of 64 dependent row loads: 66 us).
+#define FM_BG_PER_WAVE 8
 __global__ __launch_bounds__(256) void fm_bg_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B, float k1,
                                                     float k2, float* __restrict__ E, int np) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void fm_bg_kernel(const _Float16* __restrict__
   float s0[4], t0[4];
   rowv((long)b * n, s0);        // bg token of the scene cloud
   rowv((long)(B + b) * n, t0);  // bg token of the template cloud
-  for (int o = (blockIdx.x * 4 + wave) * 64, e = o + 64; o < e; ++o) {
+  for (int o = (blockIdx.x * 4 + wave) * FM_BG_PER_WAVE, e = o + FM_BG_PER_WAVE; o < e; ++o) {
     if (o >= 2 * np + 1) break;
     float y[4];
     float d;
@@ -245,9 +246,11 @@ __global__ __launch_bounds__(256) void fm_merge_sums_kernel(const float* __restr
   if (i < np) {
     const float* rp = rowpart + ((size_t)b * np + i) * slots;
     float s = 0.f;
-    for (int k = 0; k < slots - 1; ++k) s += rp[k];
+#pragma unroll 8
+    for (int k = 0; k < slots - 1; ++k) s += rp[k];  // (slots - 1 = 2 np / 128: a multiple of 8; same ascending order)
     rsum[(size_t)b * (np + 1) + 1 + i] = s + Eb[(size_t)(1 + i) * lde];  // + E[n][0]
     float c = 0.f;
+#pragma unroll 8
     for (int k = 0; k < slots - 1; ++k) c += colpart[((size_t)b * slots + k) * np + i];
     csum[(size_t)b * (np + 1) + 1 + i] = c + Eb[1 + i];                    // + E[0][m]
   }
@@ -537,7 +540,7 @@ extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const 
   hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, fh, fl);
   hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * nt * nt)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
                      sam6d_half_for(3), np);
-  hipLaunchKernelGGL(fm_bg_kernel, dim3(cdiv(2 * np + 1, 256), B), dim3(256), 0, s, fh, fl, B, k1, k2, E, np);
+  hipLaunchKernelGGL(fm_bg_kernel, dim3(cdiv(2 * np + 1, 4 * FM_BG_PER_WAVE), B), dim3(256), 0, s, fh, fl, B, k1, k2, E, np);
   hipLaunchKernelGGL(fm_merge_sums_kernel, dim3(np / 256 + 1, B), dim3(256), 0, s, rowpart, colpart, E, rsum, csum, np);
   hipLaunchKernelGGL(fm_labels_kernel, dim3(slabs, B, chunks), dim3(256), 0, s, E, rsum, csum, label1, pbest, pidx, np, rowbest, rowidx);
   hipLaunchKernelGGL(fm_merge_labels_kernel, dim3(np / 256, B), dim3(256), 0, s, pbest, pidx, label2, np);
