@@ -139,6 +139,10 @@ int sam6d_pack_panels(const float* W, long ldw, int rows, int k0, int ksteps, fl
 long sam6d_rpe_front_image_bytes(void);
 int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc, float* qkv,
                     float* qp, float* qd, long M, void* stream);
+/* The same launch with the values written TRANSPOSED per cloud of n tokens, vT (M / n, 256, ldp) -- the W operand of the P.v product
+ * (sam6d_gemm_nt_b2) -- instead of into the v third of qkv (which is then left untouched): no separate sam6d_transpose pass. */
+int sam6d_rpe_front_vt(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc, float* qkv,
+                       float* qp, float* qd, long M, float* vT, int n, int ldp, void* stream);
 long sam6d_token_block_image_bytes(int mode);
 long sam6d_linattn_kv_image_bytes(void);
 int sam6d_linattn_kv_pack(const float* kvT, int B, void* image, float* inv, void* stream);

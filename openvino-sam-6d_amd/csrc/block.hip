@@ -747,6 +747,8 @@ struct RfArgs {
   float* qd;                 // (M * 4, 32)
   long M;
   float inv_qkv, inv_wp, inv_dc;
+  float* vT;                 // optional: (M / n clouds, 256, ldp) the values transposed per cloud (the W operand of the P.v GEMM);
+  int n, ldp;                //   then the v third of qkv is not written
 };
 
 __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
@@ -833,8 +835,18 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
     c0 = f32x4{c0[0] * inv0 + b0.x, c0[1] * inv0 + b0.y, c0[2] * inv0 + b0.z, c0[3] * inv0 + b0.w};
     c1 = f32x4{c1[0] * inv0 + b1.x, c1[1] * inv0 + b1.y, c1[2] * inv0 + b1.z, c1[3] * inv0 + b1.w};
     if (valid) {
-      *reinterpret_cast<float4*>(orow + 32 * j + 4 * fg) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-      *reinterpret_cast<float4*>(orow + 32 * j + 16 + 4 * fg) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      if (j >= 16 && a.vT) {  // v channel c of token tok of its cloud -> vT[cloud][c][tok]: 16 consecutive tokens per lane group
+        float* vt = a.vT + (size_t)(row / a.n) * 256 * a.ldp + (row % a.n);
+        const int cb = 32 * (j - 16) + 4 * fg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vt[(size_t)(cb + r) * a.ldp] = c0[r];
+          vt[(size_t)(cb + 16 + r) * a.ldp] = c1[r];
+        }
+      } else {
+        *reinterpret_cast<float4*>(orow + 32 * j + 4 * fg) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        *reinterpret_cast<float4*>(orow + 32 * j + 16 + 4 * fg) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+      }
     }
     if constexpr (j < 8) {
       qa[2 * j] = c0;
@@ -880,8 +892,19 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
 
 extern "C" long sam6d_rpe_front_image_bytes(void) { return RF_IMAGE_BYTES; }
 
+static int rpe_front_launch(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc,
+                            float* qkv, float* qp, float* qd, long M, float* vT, int n, int ldp, void* stream);
 extern "C" int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc,
                                float* qkv, float* qp, float* qd, long M, void* stream) {
+  return rpe_front_launch(x, wimage, bias_qkv, inv_qkv, inv_wp, inv_dc, qkv, qp, qd, M, nullptr, 1, 1, stream);
+}
+extern "C" int sam6d_rpe_front_vt(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc,
+                                  float* qkv, float* qp, float* qd, long M, float* vT, int n, int ldp, void* stream) {
+  SAM6D_REQUIRE(vT && n > 0 && ldp >= n && M % n == 0, "rpe_front_vt: vT (M / n, 256, ldp) needs n > 0, ldp >= n, M a multiple of n");
+  return rpe_front_launch(x, wimage, bias_qkv, inv_qkv, inv_wp, inv_dc, qkv, qp, qd, M, vT, n, ldp, stream);
+}
+static int rpe_front_launch(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc,
+                            float* qkv, float* qp, float* qd, long M, float* vT, int n, int ldp, void* stream) {
   SAM6D_REQUIRE(x && wimage && bias_qkv && qkv && qp && qd && M >= 0, "rpe_front: bad arguments");
   SAM6D_REQUIRE(((((size_t)x) | ((size_t)wimage) | ((size_t)bias_qkv) | ((size_t)qkv) | ((size_t)qp) | ((size_t)qd)) & 15) == 0,
                 "rpe_front: pointers must be 16-byte aligned");
@@ -894,7 +917,7 @@ extern "C" int sam6d_rpe_front(const float* x, const void* wimage, const float* 
       return (int)e;
     }
   }
-  RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc};
+  RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc, vT, n, ldp};
   hipLaunchKernelGGL(rpe_front_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("rpe_front");
 }

@@ -541,10 +541,12 @@ def rpe_self_layer_fused(x, G, L):
         qkv = _empty((M, 3 * C), x)
         qp = _empty((M, H * C), x)
         qd = _empty((M * H, 32), x)
+        ldp = (n + 3) // 4 * 4
+        vT = _empty((Bp, C, ldp), x)  # the values land transposed per cloud (the P.v operand): no transpose pass
         with _Timed("rpe_front"):
-            _lib.call("sam6d_rpe_front", _p(x2), fr["img"].data_ptr(), _p(L["qkv"].b), fr["inv"][0], fr["inv"][1], fr["inv"][2], _p(qkv),
-                      _p(qp), _p(qd), M, _s())
-        return _rpe_self_tail(x, x2, G, L, qkv, qp, qd)
+            _lib.call("sam6d_rpe_front_vt", _p(x2), fr["img"].data_ptr(), _p(L["qkv"].b), fr["inv"][0], fr["inv"][1], fr["inv"][2], _p(qkv),
+                      _p(qp), _p(qd), M, _p(vT), n, ldp, _s())
+        return _rpe_self_tail(x, x2, G, L, qkv, qp, qd, vT)
     qkv = linear(x2, L["qkv"])  # (M, 768): q | k | v
     qp = _empty((M, H * C), x)
     # (act 16: the two folds of the geometric embedding into the query stay at fp16 x3 in matmul mode 2 -- "fp32 geometry")
@@ -554,7 +556,7 @@ def rpe_self_layer_fused(x, G, L):
     return _rpe_self_tail(x, x2, G, L, qkv, qp, qd)
 
 
-def _rpe_self_tail(x, x2, G, L, qkv, qp, qd):
+def _rpe_self_tail(x, x2, G, L, qkv, qp, qd, vT=None):
     """q.k^T, geometric scores + softmax, P.v and the layer tail of rpe_self_layer_fused."""
     Bp, n, _ = x.shape
     M = Bp * n
@@ -565,8 +567,9 @@ def _rpe_self_tail(x, x2, G, L, qkv, qp, qd):
     with _Timed("rpe_score_kernel"):
         _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd),
                   _p(qk), _p(P), M, n, ldp, _s())
-    vT = _empty((Bp, C, ldp), x)
-    _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())
+    if vT is None:
+        vT = _empty((Bp, C, ldp), x)
+        _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())
     hid = _empty((M, C), x)
     gemm_b2(P, vT, hid, n, 64, n, H * ldp, ldp, C, Bp, n * H * ldp, C * ldp, n * C, H, ldp, 64 * ldp, 64)
     return _post_attention(hid, x2, L).reshape(Bp, n, C)

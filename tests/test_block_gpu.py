@@ -298,6 +298,35 @@ def test_rpe_front_vs_fp64(dev):
         assert err < 2e-6, "%s: relative error %.2e" % (what, err)
 
 
+@pytest.mark.parametrize("Bp,n", [(3, 197), (2, 50), (5, 64)])
+def test_rpe_front_transposed_values(dev, Bp, n):
+    """sam6d_rpe_front_vt writes the values transposed per cloud (the P.v operand) instead of the v third of qkv: the same bits as
+    sam6d_rpe_front + sam6d_transpose, q / k / qp / qd unchanged."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(Bp * 10 + n)
+    M = Bp * n
+    mk = lambda o, i: pem.Linear((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i), (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    qkv = mk(768, 256)
+    L = dict(qkv=pem.Linear(qkv.w.to(dev), qkv.b.to(dev)), wpT=((torch.rand(256, 256, generator=gen) * 2 - 1) / 16).to(dev))
+    fr = pem.pack_rpe_front(L, (torch.randn(32, 256, generator=gen) * 0.1).to(dev).contiguous())
+    x = torch.randn(M, 256, generator=gen).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ldp = (n + 3) // 4 * 4
+    a = [torch.zeros(M, 768, device=dev), torch.zeros(M, 1024, device=dev), torch.zeros(M * 4, 32, device=dev)]
+    b = [torch.zeros(M, 768, device=dev), torch.zeros(M, 1024, device=dev), torch.zeros(M * 4, 32, device=dev)]
+    _lib.call("sam6d_rpe_front", x.data_ptr(), fr["img"].data_ptr(), L["qkv"].b.data_ptr(), fr["inv"][0], fr["inv"][1], fr["inv"][2],
+              a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), M, st)
+    vT_ref = torch.zeros(Bp, 256, ldp, device=dev)
+    _lib.call("sam6d_transpose", pem._p(a[0], 512), 768, n * 768, Bp, n, 256, pem._p(vT_ref), ldp, 256 * ldp, st)
+    vT = torch.zeros(Bp, 256, ldp, device=dev)
+    _lib.call("sam6d_rpe_front_vt", x.data_ptr(), fr["img"].data_ptr(), L["qkv"].b.data_ptr(), fr["inv"][0], fr["inv"][1], fr["inv"][2],
+              b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), M, vT.data_ptr(), n, ldp, st)
+    torch.cuda.synchronize()
+    assert torch.equal(vT, vT_ref), "transposed values"
+    assert torch.equal(a[0][:, :512], b[0][:, :512]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert float(b[0][:, 512:].abs().max()) == 0.0  # the v third of qkv is left untouched
+
+
 @pytest.mark.parametrize("M,N,K,ws", [(700, 256, 256, 1.0), (5000, 768, 256, 1.0e-3), (300, 32, 256, 40.0), (129, 130, 96, 1.0)])
 def test_gemm_presplit_weights_vs_fp64(dev, M, N, K, ws):
     """sam6d_gemm_nt_w16 (weights cut into fp16 hi / lo once, with a power-of-two pack scale) against float64 and against the
