@@ -140,7 +140,8 @@ long sam6d_rpe_front_image_bytes(void);
 int sam6d_rpe_front(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc, float* qkv,
                     float* qp, float* qd, long M, void* stream);
 /* The same launch with the values written TRANSPOSED per cloud of n tokens, vT (M / n, 256, ldp) -- the W operand of the P.v product
- * (sam6d_gemm_nt_b2) -- instead of into the v third of qkv (which is then left untouched): no separate sam6d_transpose pass. */
+ * (sam6d_gemm_nt_b2), i.e. the `torch.matmul(attention_scores, v)` of PEM/model/transformer.py:416 -- instead of into the v third of
+ * qkv (which is then left untouched): no separate sam6d_transpose pass. */
 int sam6d_rpe_front_vt(const float* x, const void* wimage, const float* bias_qkv, float inv_qkv, float inv_wp, float inv_dc, float* qkv,
                        float* qp, float* qd, long M, float* vT, int n, int ldp, void* stream);
 long sam6d_token_block_image_bytes(int mode);
