@@ -266,6 +266,10 @@ int sam6d_soft_assign(const float* att, int B, int R, int C, float* rmax, float*
  * arithmetic, same summation orders: PEM/utils/model_utils.py:229-240).  rc < 0 for larger matrices. */
 int sam6d_coarse_soft_assign(const float* att, int B, int R, int C, float* rmax, float* rsum, float* cmax, float* csum, int* label1,
                              int* label2, float* weights, float* w1, void* stream);
+/* replaces pairwise_distance(x, y) (PEM/utils/model_utils.py:101-128; normalized = False, channel-last): x (B,N,3), y (B,M,3) ->
+ * out (B,N,M) = clamp((|x|^2 - 2 x.y) + |y|^2, min = 0) with the bits of torch's CPU evaluation (K = 3 matmul = an fma chain, plain
+ * sums of squares: SURVEY 8c n1/n2).  The path's kernels inline the same device function; this entry is the direct check. */
+int sam6d_pairwise_distance(const float* x, const float* y, int B, int N, int M, float* out, void* stream);
 /* Sampling weights (S[1:,1:] * w1 * w2) ** 1.5 -> (B,(R-1)*(C-1)), w1 (B,R-1) (PEM/utils/model_utils.py:234-238). */
 int sam6d_coarse_weights(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
                          const float* csum, const int* label1, const int* label2, float* weights, float* w1,

@@ -916,6 +916,7 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
       sam6d_set_error("rpe_front: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
     }
+    sam6d_setup_done_on_device(&done);
   }
   RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc, vT, n, ldp};
   hipLaunchKernelGGL(rpe_front_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
@@ -955,6 +956,7 @@ static int tb_set_attr() {
     if (!rc) rc = tb_attr(token_block_kernel<0, 4, 4>, TB_LDS_BYTES(4));
     if (!rc) rc = tb_attr(token_block_kernel<1, 8, 4>, TB_LDS_BYTES(4));
     if (rc) return rc;
+    sam6d_setup_done_on_device(&done0);
   }
   return 0;
 }
@@ -985,7 +987,7 @@ extern "C" int sam6d_linattn_layer(const float* D, const void* wimage, const flo
   if (B == 0) return 0;
   int rc = tb_set_attr();
   if (rc) return rc;
-  const int tok = 16 * tb_shape();
+  const int tok = tb_shape() == 8 ? 128 : 64;  // tokens per workgroup of the kernel shape launched below
   const int tiles = (I - row0 + tok - 1) / tok;
   SAM6D_REQUIRE((long)B * tiles < 2147483647L, "linattn_layer: too many tiles");
   TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps,

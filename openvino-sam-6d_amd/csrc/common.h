@@ -184,19 +184,28 @@ __device__ __forceinline__ void sam6d_split2_f16(float a, float b, unsigned& hi2
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// One-time per-DEVICE setup (hipFuncSetAttribute, CU count ...): `done` is a bit mask over device ordinals owned by the call site;
-// returns true the first time the calling thread's current device is seen.  A process that drives several GPUs gets every device
-// initialised, instead of device 0's state being reused for all of them.
-static inline bool sam6d_first_use_on_device(unsigned long long* done, int* dev_out = nullptr) {
+// One-time per-DEVICE setup (hipFuncSetAttribute, CU count ...): `done` is a bit mask over device ordinals owned by the call site.
+// sam6d_first_use_on_device returns true while the calling thread's current device has not COMPLETED its setup; the call site runs the
+// setup and, only after it succeeded, calls sam6d_setup_done_on_device -- a failed setup is retried by the next call instead of being
+// skipped.  The mask is read / updated atomically: two host threads driving different GPUs may both run the (idempotent) setup of
+// their own device, neither can lose the other's bit.  A process that drives several GPUs gets every device initialised, instead of
+// device 0's state being reused for all of them.  Ordinals >= SAM6D_MAX_DEVICES: dev_out = -1, the call site rejects the launch.
+#define SAM6D_MAX_DEVICES 64
+static inline bool sam6d_first_use_on_device(const unsigned long long* done, int* dev_out = nullptr) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev < 0 || dev >= SAM6D_MAX_DEVICES) {
+    if (dev_out) *dev_out = -1;
+    return true;  // never cached: the setup runs (or the call site rejects the ordinal) on every call
+  }
   if (dev_out) *dev_out = dev;
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (*done & bit) return false;
-  *done |= bit;
-  return true;
+  return ((__atomic_load_n(done, __ATOMIC_ACQUIRE) >> dev) & 1ull) == 0;
 }
-#define SAM6D_MAX_DEVICES 64
+static inline void sam6d_setup_done_on_device(unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SAM6D_MAX_DEVICES) return;
+  (void)__atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELEASE);
+}
 
 // matmul mode 2 (fp16 single product) per kernel family: bit 0 generic GEMM, 1 block kernels, 2 cross attention, 3 fine similarity.
 // SAM6D_HALF_MASK (environment, read once; default 15 = all) narrows it -- a bisecting aid, see DESIGN "Mode 2".

@@ -370,6 +370,7 @@ static int h3_reserve_lds() {
       sam6d_set_error("geo_embed_h3: cannot reserve %d bytes of LDS: %s", GH_LDS_BYTES, hipGetErrorString(e));
       return (int)e;
     }
+    sam6d_setup_done_on_device(&attr_done);
   }
   return 0;
 }
@@ -590,6 +591,7 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
   static unsigned long long cheb_done = 0;
   int dev = 0;
   if (sam6d_first_use_on_device(&cheb_done, &dev)) {
+    SAM6D_REQUIRE(dev >= 0, "geo_embed_cheb: device ordinal beyond SAM6D_MAX_DEVICES");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(geo_cheb_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS_BYTES);
     int cu = 0;
@@ -599,9 +601,10 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
                       hipGetErrorString(e));
       return e != hipSuccess ? (int)e : SAM6D_EINVAL;
     }
-    n_cu_dev[dev & 63] = cu;
+    n_cu_dev[dev] = cu;
+    sam6d_setup_done_on_device(&cheb_done);
   }
-  const int n_cu = n_cu_dev[dev & 63];
+  const int n_cu = n_cu_dev[dev];
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,

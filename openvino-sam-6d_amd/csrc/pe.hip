@@ -336,6 +336,7 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
         sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
         return (int)e;
       }
+      sam6d_setup_done_on_device(&attr_h3);
     }
     // persistent waves: 3 workgroups of 4 waves fit one CU's LDS (3 x 48.6 KB) -> 768 workgroups fill the 256 CUs once
     const long want = (total + PH_WAVES - 1) / PH_WAVES;
@@ -352,6 +353,7 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
         sam6d_set_error("pe_mlp_max: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
         return (int)e;
       }
+      sam6d_setup_done_on_device(&attr_set);
     }
     hipLaunchKernelGGL(pe_mlp_max_kernel, grid, dim3(PM_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, total, W1, sc1,
                        sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);

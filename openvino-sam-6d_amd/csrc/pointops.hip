@@ -266,13 +266,15 @@ extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int
     static unsigned long long resident_done = 0;
     int dev = 0;
     if (sam6d_first_use_on_device(&resident_done, &dev)) {
+      SAM6D_REQUIRE(dev >= 0, "furthest_point_sampling: device ordinal beyond SAM6D_MAX_DEVICES");
       int cu = 0, per_cu = 0;
       hipError_t e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_grid_kernel<4>, 256, 0);
-      resident_dev[dev & 63] = (e == hipSuccess && cu > 0 && per_cu > 0) ? cu * (per_cu > 1 ? per_cu - 1 : 1) : 0;  // (margin: the API can be one high)
+      resident_dev[dev] = (e == hipSuccess && cu > 0 && per_cu > 0) ? cu * (per_cu > 1 ? per_cu - 1 : 1) : 0;  // (margin: the API can be one high)
       (void)hipGetLastError();
+      if (e == hipSuccess) sam6d_setup_done_on_device(&resident_done);  // (a failed query: one-workgroup kernel now, asked again next call)
     }
-    const int max_resident = resident_dev[dev & 63];
+    const int max_resident = resident_dev[dev];
     const long cap_wg = max_resident < FPS_GRID_MAX_WG ? max_resident : FPS_GRID_MAX_WG;
     const bool grid_ok = G * B <= cap_wg && (size_t)(m + 2) * 8 + 8 <= (size_t)N * 4;  // the round slots live in the cloud's own row
     if (grid_ok) {

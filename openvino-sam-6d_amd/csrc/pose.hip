@@ -403,6 +403,7 @@ extern "C" int sam6d_coarse_soft_assign(const float* att, int B, int R, int C, f
       sam6d_set_error("coarse_soft_assign: cannot reserve LDS: %s", hipGetErrorString(e));
       return (int)e;
     }
+    sam6d_setup_done_on_device(&cas_done);
   }
   hipLaunchKernelGGL(coarse_assign_kernel, dim3(B), dim3(1024), CAS_LDS_BYTES(R, C), (hipStream_t)stream, att, R, C, rmax, rsum, cmax,
                      csum, label1, label2, weights, w1);
@@ -1007,4 +1008,29 @@ extern "C" int sam6d_fine_score(const float* pts1, const float* R, float* t, con
                      dis_thres, cnt_ws);
   hipLaunchKernelGGL(fine_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, cnt_ws, radius, B, N, t, score);
   SAM6D_LAUNCH_CHECK("fine_score");
+}
+
+// =========================================================================================================
+// pairwise_distance (model_utils.py:101-128) as a stand-alone entry: the K = 3 squared distances in the torch-CPU bit recipe.
+// The path's own kernels (geo_knn / geo_index, score_hyp, fine_near) inline the same pdist3(); this entry exposes the recipe at the
+// reference's call signature so that it is checked directly against tests/golden/pairwise.npz.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void pairwise_distance_kernel(const float* __restrict__ x, const float* __restrict__ y, int N, int M,
+                                                                float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int n = blockIdx.y;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float* xp = x + ((size_t)b * N + n) * 3;
+  const float* yp = y + ((size_t)b * M + m) * 3;
+  const float x0 = xp[0], x1 = xp[1], x2 = xp[2], y0 = yp[0], y1 = yp[1], y2 = yp[2];
+  out[((size_t)b * N + n) * M + m] = pdist3(x0, x1, x2, sqnorm3(x0, x1, x2), y0, y1, y2, sqnorm3(y0, y1, y2));
+}
+
+extern "C" int sam6d_pairwise_distance(const float* x, const float* y, int B, int N, int M, float* out, void* stream) {
+  SAM6D_REQUIRE(x && y && out, "pairwise_distance: null pointer");
+  SAM6D_REQUIRE(B >= 0 && B <= 65535 && N >= 0 && N <= 65535 && M >= 0, "pairwise_distance: bad sizes (B, N <= 65535)");
+  if (B == 0 || N == 0 || M == 0) return 0;
+  hipLaunchKernelGGL(pairwise_distance_kernel, dim3(cdiv(M, 256), N, B), dim3(256), 0, (hipStream_t)stream, x, y, N, M, out);
+  SAM6D_LAUNCH_CHECK("pairwise_distance");
 }

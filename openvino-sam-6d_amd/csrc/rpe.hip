@@ -462,6 +462,7 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
   static unsigned long long rpe_done = 0;
   int dev = 0;
   if (sam6d_first_use_on_device(&rpe_done, &dev)) {
+    SAM6D_REQUIRE(dev >= 0, "rpe_scores: device ordinal beyond SAM6D_MAX_DEVICES");
     int cu = 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
@@ -470,9 +471,10 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
       sam6d_set_error("rpe_scores: cannot reserve %d bytes of LDS / query the device: %s", lds_max, hipGetErrorString(e));
       return e != hipSuccess ? (int)e : SAM6D_EINVAL;
     }
-    n_cu_dev[dev & 63] = cu;
+    n_cu_dev[dev] = cu;
+    sam6d_setup_done_on_device(&rpe_done);
   }
-  const int n_cu = n_cu_dev[dev & 63];
+  const int n_cu = n_cu_dev[dev];
   const float scale = 0.125f;  // 1/sqrt(64): d_model 256, 4 heads (coarse_point_matching.py:24, fine_point_matching.py:31)
   const int mpad = ((n + 15) / 16) * 16;
   const int per_wave = (RP_QW_FLOATS + 4 * mpad) * 4;

@@ -302,6 +302,7 @@ extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void
       sam6d_set_error("cross_attention: cannot reserve %d bytes of LDS: %s", XA_LDS, hipGetErrorString(e));
       return (int)e;
     }
+    sam6d_setup_done_on_device(&done);
   }
   XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2)};
   hipLaunchKernelGGL(xattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);

@@ -18,6 +18,20 @@ def sample_pts_feats(pts, feats, npoint=2048, return_index=False):
     return (sp, sf, idx) if return_index else (sp, sf)
 
 
+def pairwise_distance(x, y, normalized=False, channel_first=False):
+    """model_utils.py:101-128 for 3-d points (the only use on the path): squared distances with the bits of the reference's CPU
+    evaluation (sam6d_pairwise_distance)."""
+    if normalized:
+        raise NotImplementedError("pairwise_distance: the normalized form is not used by the inference path")
+    if channel_first:
+        x, y = x.transpose(-1, -2), y.transpose(-1, -2)
+    if x.shape[-1] != 3 or y.shape[-1] != 3 or x.shape[:-2] != y.shape[:-2]:
+        raise NotImplementedError("pairwise_distance: (*, N, 3) x (*, M, 3) point clouds with equal batch dimensions")
+    lead = x.shape[:-2]
+    return _pem.pairwise_distance(x.reshape(-1, x.shape[-2], 3).contiguous(), y.reshape(-1, y.shape[-2], 3).contiguous()).reshape(
+        *lead, x.shape[-2], y.shape[-2])
+
+
 def compute_feature_similarity(feat1, feat2, type='cosine', temp=1.0, normalize_feat=True):
     """model_utils.py:131-153 (cosine with normalisation, the configuration PEM uses)."""
     if type != 'cosine' or not normalize_feat or feat1.shape[1] != feat2.shape[1]:

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sam6d_crop_masked_points": [c_p, c_p, c_i, c_i, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p, c_p, c_p, c_p],
     "sam6d_radius_filter": [c_i, c_i, c_p, c_f, c_p, c_p, c_p, c_p, c_p],
     "sam6d_choose_points": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    "sam6d_pairwise_distance": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "sam6d_fine_score": [c_p] * 6 + [c_i] * 3 + [c_f, c_p, c_p, c_p],
     "sam6d_fine_match_workspace_bytes": [c_i],
     "sam6d_fine_match_workspace_bytes_n": [c_i, c_i],

@@ -23,18 +23,55 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Flags:
+    """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
+    ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front")
+
+    def __init__(self):
+        env = os.environ.get
+        self.mode = int(_lib.load().sam6d_get_matmul_mode())
+        self.w16 = self.mode >= 1 and env("SAM6D_W16", "1") == "1"
+        self.fused_block = self.mode >= 1 and env("SAM6D_FUSED_BLOCK", "1") == "1"
+        self.fused_ln = self.mode >= 1 and env("SAM6D_FUSED_LN", "0") == "1"
+        self.fused_front = self.fused_block and env("SAM6D_FUSED_FRONT", "1") == "1"
+
+
+_FLAGS = None
+_DEPTH = 0
+
+
+def _flags():
+    """Inside a public entry point (on_tensor_device): the switches as they were when it was entered; outside: read afresh."""
+    global _FLAGS
+    if _FLAGS is not None:
+        return _FLAGS
+    f = _Flags()
+    if _DEPTH > 0:
+        _FLAGS = f
+    return f
+
+
 def on_tensor_device(fn):
     """Run `fn` with the device of its first tensor argument current: the launches go to torch's current stream OF THAT DEVICE and
-    torch.empty workspaces land there, also when the caller's current device is another GPU of the node."""
+    torch.empty workspaces land there, also when the caller's current device is another GPU of the node.  The outermost decorated call
+    also fixes the process-wide switches (_flags) for its whole launch sequence."""
     import functools
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
+        global _DEPTH, _FLAGS
         dev = next((a.device for a in args if torch.is_tensor(a)), None)
         if dev is None or dev.type != "cuda":
             raise RuntimeError("%s: needs HIP device tensors (this build has no CPU path)" % fn.__name__)
-        with torch.cuda.device(dev):
-            return fn(*args, **kwargs)
+        _DEPTH += 1
+        try:
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+        finally:
+            _DEPTH -= 1
+            if _DEPTH == 0:
+                _FLAGS = None
     return wrapper
 
 
@@ -268,7 +305,7 @@ def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, 
          colscale=None, batch=1, sA=0, sW=0, sC=0, sR=0, divisor=1.0, act=0, w16=None):
     """w16 = Linear.w16() of the weight `W` belongs to: the pre-split halves are used in the split-precision modes."""
     def launch():
-        if w16 is not None and K >= 32 and _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_W16", "1") == "1":
+        if w16 is not None and K >= 32 and _flags().w16:
             hi, lo, sc = w16
             _lib.call("sam6d_gemm_nt_w16", _p(A, a_off), _p(W, w_off), hi.data_ptr() + 2 * w_off, lo.data_ptr() + 2 * w_off, sc, _p(bias),
                       _p(colscale), _p(residual, r_off), _p(out, c_off), M, N, K, lda, ldw, ldc, ldr, batch, sA, sW, sC, sR,
@@ -317,7 +354,7 @@ def _post_attention(hidden, x2d, L):
         return out
     # SAM6D_FUSED_LN=1: projection + residual + LayerNorm in one launch (sam6d_gemm_ln256).  Off by default: measured 1 % slower
     # than the two launches (64-row tiles at 184 registers and 4-byte stores cost what the saved LayerNorm pass gives back).
-    if _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_FUSED_LN", "0") == "1":
+    if _flags().fused_ln:
         y = gemm_ln(hidden, L["lin"], x2d, L["n1"])
         h = linear(y, L["exp"], act=1)
         return gemm_ln(h, L["sq"], y, L["n2"])
@@ -329,7 +366,7 @@ def _post_attention(hidden, x2d, L):
 def _fused_block():
     """The fused transformer-block kernels (csrc/block.hip) serve the split-precision mode; SAM6D_FUSED_BLOCK=0 keeps the
     launch-per-op path (also what matmul mode 0, the exact fp32 MFMA reference arithmetic, uses)."""
-    return _lib.load().sam6d_get_matmul_mode() >= 1 and os.environ.get("SAM6D_FUSED_BLOCK", "1") == "1"
+    return _flags().fused_block
 
 
 def gemm_ln(x, lin, residual, norm, eps=1e-5):
@@ -376,13 +413,20 @@ def geo_embedding(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     flag = knn.data_ptr() + 4 * B * n * angle_k
     factor_a = 180.0 / (sigma_a * math.pi)
     _lib.call("sam6d_geo_indices", _p(points_bg), B, n, float(sigma_d), float(factor_a), angle_k, _p(knn), _p(idx), _s())
-    if _lib.load().sam6d_get_matmul_mode() >= 1:
+    if _flags().mode >= 1 and not geo_images_in_range(W):
+        # proj_d / proj_a (or their Chebyshev coefficients) x 1024 leave the fp16 range: the split-precision images of this weight set
+        # would hold inf.  The exact fp32 kernel (mode 0's) computes the embedding instead -- slower, never wrong.
+        with _Timed("geo_embed_kernel"):
+            _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
+                      _p(W.geo_a.b), C, flag, 0, _p(out), _s())
+        return out
+    if _flags().mode >= 1:
         lst = _empty((B * n * n + 1,), points_bg, torch.int32)  # [count | pair ids outside the Chebyshev range]
         pos = _empty((B * n * n,), points_bg, torch.int32)  # pair -> list slot or -1
         with _Timed("geo_embed_kernel"):
             _lib.call("sam6d_geo_embed_cheb", _p(idx), B * n * n, geo_cheb_packed(W).data_ptr(), float(GEO_XMAX), _p(W.div_term),
                       geo_packed(W).data_ptr(), _p(W.geo_d.b), _p(W.geo_a.b), C, flag, _p(pos), _p(lst), _p(out), _s())
-    if _lib.load().sam6d_get_matmul_mode() >= 1:
+    if _flags().mode >= 1:
         # indices beyond the fast sincos range (flag set on the device): this launch redoes the call exactly; otherwise
         # it returns immediately
         _lib.call("sam6d_geo_embed", _p(idx), B * n * n, _p(W.div_term), _p(W.geo_d.w), _p(W.geo_d.b), _p(W.geo_a.w),
@@ -423,7 +467,10 @@ def geo_cheb_packed(W):
     if pk is None:
         import numpy as np
         c = np.stack([cheb_coefficients(W.geo_d.w, W.div_term), cheb_coefficients(W.geo_a.w, W.div_term)], 0) * 1024.0
-        c32 = c.astype(np.float32)
+        # the images hold (coefficient x 1024) and (weight x 1024) as fp16 hi / lo halves: both matrices of both must stay finite there
+        wmax = max(float(W.geo_d.w.abs().max()), float(W.geo_a.w.abs().max())) * 1024.0
+        W._geo_img_fits = bool(np.abs(c).max() < 60000.0 and wmax < 60000.0)
+        c32 = np.clip(c, -65000.0, 65000.0).astype(np.float32)  # (an out-of-range image is never used: geo_images_in_range)
         hi = c32.astype(np.float16)
         lo = (c32 - hi.astype(np.float32)).astype(np.float16)
         img = np.concatenate([hi, lo, np.zeros((2, C, 8), np.float16)], axis=2)  # (2, 256, 72 halves = 144 B)
@@ -431,8 +478,16 @@ def geo_cheb_packed(W):
         W._geo_cheb = pk
         # rpe_score_kernel converts the projected angular embedding (x 1024) to fp16 hi / lo for its second contraction: |T_p| <= 1, so
         # sum_p |1024 c[ch][p]| bounds every value it can meet.  Weights beyond the fp16 range take the materialised-embedding path.
-        W._geo_cheb_fits = bool(np.abs(c[1]).sum(axis=1).max() < 60000.0)
+        W._geo_cheb_fits = bool(W._geo_img_fits and np.abs(c[1]).sum(axis=1).max() < 60000.0)
     return pk
+
+
+def geo_images_in_range(W):
+    """True when proj_d / proj_a x 1024 and their Chebyshev coefficients x 1024 are all finite in fp16, i.e. the split-precision
+    embedding kernels (sam6d_geo_embed_cheb / _h3 and the outlier rows) can serve this weight set; otherwise geo_embedding uses the
+    exact fp32 kernel."""
+    geo_cheb_packed(W)
+    return W._geo_img_fits
 
 
 def fused_rpe_in_range(W):
@@ -533,7 +588,7 @@ def rpe_self_layer_fused(x, G, L):
     Bp, n, _ = x.shape
     M = Bp * n
     x2 = x.reshape(M, C)
-    if _fused_block() and os.environ.get("SAM6D_FUSED_FRONT", "1") == "1":
+    if _flags().fused_front:
         # qkv projection, proj_p fold and D_c fold of the query in one launch (block.hip rpe_front_kernel)
         fr = L.get("front")
         if fr is None:
@@ -775,6 +830,21 @@ def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_
 
 
 @on_tensor_device
+def pairwise_distance(x, y):
+    """PEM/utils/model_utils.py:101-128 on (B,N,3) x (B,M,3) -> (B,N,M) squared distances, torch-CPU bit recipe."""
+    from .ops import _chk
+    _chk(x, "x", torch.float32, 3)
+    _chk(y, "y", torch.float32, 3)
+    B, N, _ = x.shape
+    M = y.shape[1]
+    if y.shape[0] != B or x.shape[2] != 3 or y.shape[2] != 3:
+        raise RuntimeError("pairwise_distance: need x (B,N,3) and y (B,M,3)")
+    out = _empty((B, N, M), x)
+    _lib.call("sam6d_pairwise_distance", _p(x), _p(y), B, N, M, _p(out), _s())
+    return out
+
+
+@on_tensor_device
 def weighted_procrustes(src, ref, weights=None, weight_thresh=0.0, eps=1e-5):
     """PEM/utils/model_utils.py:343-436: (B,N,3) x2 [+ (B,N)] -> R (B,3,3), t (B,3)."""
     B, N, _ = src.shape
@@ -820,7 +890,7 @@ def fine_match(f, B, n, temp, pts2):
     return l1, l2, pred, wgt
 
 
-def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.15):
+def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.15, return_aux=False):
     """compute_feature_similarity + compute_fine_Rt (PEM/utils/model_utils.py:131-153, 308-341) from the out_proj features."""
     pts2 = pts2.contiguous()
     l1, l2, pred, wgt = fine_match(f, B, n, temp, pts2)
@@ -829,6 +899,8 @@ def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.
     score = _empty((B,), f)
     _lib.call("sam6d_fine_score", _p(pts1), _p(R), _p(t), _p(model), _p(radius), _p(l1), B, n - 1, model.shape[1], float(dis_thres),
               _p(cnt), _p(score), _s())
+    if return_aux:
+        return R, t, score, dict(l1=l1, l2=l2, pred=pred, weights=wgt)
     return R, t, score
 
 
@@ -939,10 +1011,12 @@ def fine_static(dp, df, W, cfg, shared_template=False):
     return fine_static_b(dp, D, grp, W, shared_template)
 
 
-def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None, shared_template=False):
+def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cfg, return_aux=False, D=None, shared_template=False,
+                        fused_fine=True):
     """dp (2B,N,3) stacked [scene; template], df the dense features: (2B,N,256) stacked the same way, or the pair (scene (B,N,256),
     template (B,N,256)) left where the caller holds them  (PEM/model/fine_point_matching.py:42-79, eval).
-    D: the result of fine_static() when the caller has already produced it."""
+    D: the result of fine_static() when the caller has already produced it.  fused_fine=False: the (B,N+1,N+1) attention matrix is
+    materialised (launch-per-op path; aux then carries it as `atten`), otherwise aux carries the pipeline's labels / weights."""
     Bp, N, _ = dp.shape
     B = Bp // 2
     if D is None:
@@ -953,10 +1027,10 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
                             cfg["pe_nsample2"])
     for blk in W.fine["blocks"]:
         D = sparse_to_dense_transformer(D, E, fps_idx, blk)
-    if not return_aux and N in (2048, 4096) and _fused_block():
+    if fused_fine and N in (2048, 4096) and _fused_block():
         # similarity + soft assignment as one pipeline: the (B, 2049, 2049) matrix is written once and read twice (finematch.hip)
         f = linear(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"])
-        return compute_fine_Rt_fused(f, B, N + 1, cfg["temp"], dp[:B], dp[B:], model, radius, cfg["dis_thres"])
+        return compute_fine_Rt_fused(f, B, N + 1, cfg["temp"], dp[:B], dp[B:], model, radius, cfg["dis_thres"], return_aux)
     att = feature_similarity(D, B, N + 1, W.fine["out_proj"], cfg["temp"])
     R, t, score = compute_fine_Rt(att, dp[:B], dp[B:], model, radius, cfg["dis_thres"])
     if return_aux:
@@ -981,6 +1055,14 @@ def _ensure_w16(W):
                 walk(v)
     for part in (getattr(W, "coarse", None), getattr(W, "fine", None), getattr(W, "pe", None)):
         walk(part)
+    # the RPE-front weight images of every self layer too (rpe_self_layer_fused would build them on first use -- with micro-batching
+    # on whichever slice's stream got there first, while another slice's stream could already launch with the cached image)
+    dcT = geo_dcT(W)
+    for part in (getattr(W, "coarse", None), getattr(W, "fine", None)):
+        for blk in (part or {}).get("blocks", []):
+            L = blk["self"]
+            if "front" not in L:
+                L["front"] = pack_rpe_front(L, dcT)
     W._w16_done = True
 
 
@@ -1002,7 +1084,7 @@ DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0
 
 @on_tensor_device
 def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False,
-              shared_template=False):
+              shared_template=False, init_pose=None):
     """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
@@ -1015,11 +1097,20 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     on k HIP streams (one slice's latency-bound chains beside another's dense kernels, +2 % at k = 2, twice the host launch work).
     FPS, gathers and the geometric indices of every slice are computed first, serially, on the caller's stream -- defence in
     depth for the packed-fp32 / f16-MFMA hazard described in DESIGN "Concurrency caveat" (the library is built without packed
-    fp32 instructions since).  scratch/dbg_ov.py: 0 of 60 two-slice runs differ from the serial result."""
+    fp32 instructions since).  scratch/dbg_ov.py: 0 of 60 two-slice runs differ from the serial result.
+
+    return_aux=True adds a dict of intermediates (coarse attention, sampled indices, hypotheses, scores, the coarse pose, FPS indices,
+    fine labels / weights) WITHOUT changing which kernels run.  Kernel choice is cfg's: cfg["fused_rpe"] (env SAM6D_FUSED_RPE, default on)
+    = RPE attention without the embedding tensor, cfg["fused_fine"] (env SAM6D_FUSED_FINE, default on) = the similarity + soft-assignment
+    pipeline of finematch.hip; off = the materialised launch-per-op forms.
+    init_pose = (R0 (B,3,3), t0 (B,3)): the fine stage starts from this pose instead of the coarse stage's own result (which is still
+    computed and returned in aux) -- the seam FinePointMatching.forward takes its init_R / init_t through
+    (PEM/model/fine_point_matching.py:42-46); used by the staged parity tests."""
     B = dense_pm.shape[0]
     mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
     fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() >= 1
-    fused = fused and not return_aux and fused_rpe_in_range(W)
+    fused = fused and fused_rpe_in_range(W)
+    fused_fine = bool(cfg.get("fused_fine", os.environ.get("SAM6D_FUSED_FINE", "1") == "1"))
 
     overlap = cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1")
 
@@ -1091,7 +1182,9 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         R0, t0 = c[0], c[1]
         if D is not None:
             torch.cuda.current_stream().wait_stream(side)
-        f = fine_point_matching(dp, df, E, idx, rad, mod, R0, t0, W, cfg, return_aux, D=D, shared_template=shared_template)
+        Ri, ti = (R0, t0) if init_pose is None else (init_pose[0][lo:hi].contiguous(), init_pose[1][lo:hi].contiguous())
+        f = fine_point_matching(dp, df, E, idx, rad, mod, Ri, ti, W, cfg, return_aux, D=D, shared_template=shared_template,
+                                fused_fine=fused_fine)
         if return_aux:
             b = hi - lo
             return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:b], fps_idx_o=idx[b:],

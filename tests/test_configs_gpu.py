@@ -3,7 +3,8 @@
 * config 1 -- the demo Example (real depth map, camera and CAD model; tests/golden/config1.npz, written by oracle/gen_golden.py
   fx_config1 from the reference's own modules): get_test_data geometry, template FPS, radius normalisation, then the whole matching
   path, against the reference's outputs;
-* config 2 at full size -- B = 32 proposals in one pem_match call against the CPU oracle on 8 of them;
+* config 2 at full size -- B = 32 proposals in one pem_match call (default kernels), all 32 against the CPU oracle, staged so that every
+  discrete choice is either identical or an asserted within-rounding threshold case;
 * config 4 on one GPU -- 200 proposals dealt round-robin to 8 shards, every shard through pem_match, the gathered rows put back in
   global order: bit-for-bit the unsharded result;
 * the fine stage's label / weight work (index work) against the oracle.
@@ -93,32 +94,120 @@ def test_config1_matching_path_vs_reference(dev, W):
 
 
 # ------------------------------------------------------------------------------------------------------- config 2
+def _oracle_proposal(O, inp, b, sd, cfg):
+    """The oracle on proposal b alone (O.pem_match's body, PEM/model/pose_estimation_model.py:29-55), keeping what the staged checks
+    need: the sparse clouds, both geometric embeddings, the coarse intermediates and a closure that runs the fine stage from any pose."""
+    sl = lambda k: inp[k][b:b + 1].contiguous()
+    pm, fm, po, fo, radius, model, rand = (sl(k) for k in ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model", "rand"))
+    n = cfg["coarse_npoint"]
+    bgp = torch.ones(1, 1, 3) * 100
+    spm, sfm, im = O.sample_pts_feats(pm, fm, n)
+    gm = O.geo_embedding(torch.cat([bgp, spm], 1), sd, "geo_embedding", cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    spo, sfo, io = O.sample_pts_feats(po, fo, n)
+    go = O.geo_embedding(torch.cat([bgp, spo], 1), sd, "geo_embedding", cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
+    R0, t0, caux = O.coarse_point_matching(spm, sfm, gm, spo, sfo, go, radius, model, sd, rand, cfg, False, True)
+    fine = lambda Ri, ti: O.fine_point_matching(pm, fm, gm, im, po, fo, go, io, radius, model, Ri, ti, sd, cfg)
+    R, t, s = fine(R0, t0)
+    return dict(R=R, t=t, s=s, R0=R0, t0=t0, coarse=caux, fine=fine, spm=spm, spo=spo, im=im, io=io,
+                mp=model / (radius.reshape(-1, 1, 1) + 1e-6), rand=rand)
+
+
+def _d(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
 def test_config2_full_batch_vs_oracle(dev, W, sd):
-    """B = 32 (the benchmark's step) in ONE pem_match call; the CPU oracle runs proposals 0, 5, ... one at a time."""
+    """B = 32 (the benchmark's step) in ONE pem_match call with the DEFAULT kernels, ALL 32 proposals against the CPU oracle, no waiver.
+
+    The coarse pose is a discrete choice (18 000 threshold searches, a top-300, an arg-max: PEM/utils/model_utils.py:241-275), so on
+    config 2's random features a 1e-7 difference can select another hypothesis and the end-to-end poses of such a proposal differ by
+    O(1).  The test therefore proves the chain link by link, for every proposal:
+      (1) FPS indices bit-exact; coarse attention within 1e-4;
+      (2) every sampled index is a correct first-(cum >= u) index of the ORACLE's cumulative weights of that attention up to 1e-6
+          (cum is normalised to 1), and the foreground masks are identical;
+      (3) the oracle, continued from the GPU's sampled indices, selects the GPU's coarse pose (1e-4) -- or the GPU's pick scores within
+          1e-6 relative of the oracle's best (an asserted tie) and is that hypothesis of the oracle (1e-4);
+      (4) the oracle's fine stage continued from the GPU's coarse pose gives the GPU's final pose / score (1e-4);
+      (5) the GPU's fine stage started from the ORACLE's coarse pose (pem_match(init_pose=...)) gives the oracle's final pose (1e-4).
+    Where (2) and (3) hold with identical choices, (4) is the plain end-to-end comparison."""
     from oracle import pem_oracle as O
     from sam6d_hip import pem, synth
-    inp = synth.config2_inputs(B=32, seed=1)
+    B = 32
+    cfg = O.DEFAULT_CFG
+    inp = synth.config2_inputs(B=B, seed=1)
     d = {k: v.to(dev) for k, v in inp.items()}
-    R, t, s = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W, d["rand"])
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    R, t, s, aux = pem.pem_match(*[d[k] for k in keys], W, d["rand"], return_aux=True)
+    R_plain, t_plain, s_plain = pem.pem_match(*[d[k] for k in keys], W, d["rand"])
     torch.cuda.synchronize()
+    assert torch.equal(R, R_plain) and torch.equal(t, t_plain) and torch.equal(s, s_plain), "return_aux changed the result"
     assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(s).all()
-    _close(torch.linalg.det(R.cpu().double()).float(), torch.ones(32), 1e-5, "proper rotations")
-    picks = [0, 5, 9, 14, 18, 23, 27, 31]
+    _close(torch.linalg.det(R.cpu().double()).float(), torch.ones(B), 1e-5, "proper rotations")
+    ca = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in aux["coarse"].items()}
+    Rc, tc, sc = R.cpu(), t.cpu(), s.cpu()
+    R0c, t0c = aux["init_R"].cpu(), aux["init_t"].cpu()
+    fps_m, fps_o = aux["fps_idx_m"].cpu(), aux["fps_idx_o"].cpu()
     torch.set_num_threads(min(16, torch.get_num_threads() or 8))
-    off = []
-    for b in picks:
-        sl = lambda k: inp[k][b:b + 1].contiguous()
-        with torch.no_grad():
-            oR, ot, os_ = O.pem_match(sl("dense_pm"), sl("dense_fm"), sl("dense_po"), sl("dense_fo"), sl("radius"), sl("model"), sd,
-                                      sl("rand"))
-        d = max(float((R[b:b + 1].cpu() - oR).abs().max()), float((t[b:b + 1].cpu() - ot).abs().max()),
-                float((s[b:b + 1].cpu() - os_).abs().max()))
-        if d > 1e-4:
-            off.append((b, d))
-    # Config 2's features are random: there is no true pose, and a proposal whose best two coarse hypotheses score within rounding of
-    # each other ends on a different fine pose when ANY product is rounded differently (proposal 31 of this seed is one: it flips between
-    # arithmetic variants of this library that agree to 1e-6 everywhere else).  Seven of the eight must match at 1e-4.
-    assert len(off) <= 1, "proposals off by more than 1e-4 vs the CPU oracle: %s" % off
+    n1 = cfg["nproposal1"]
+    oR0, ot0, oR, ot, os_ = [], [], [], [], []
+    n_e2e_same, n_idx_diff, n_tie, worst = 0, 0, 0, dict(att=0.0, e2e=0.0, fine_given_pose=0.0)
+    with torch.no_grad():
+        for b in range(B):
+            o = _oracle_proposal(O, inp, b, sd, cfg)
+            oR0.append(o["R0"]); ot0.append(o["t0"]); oR.append(o["R"]); ot.append(o["t"]); os_.append(o["s"])
+            tag = "proposal %d: " % b
+            # (1)
+            assert torch.equal(fps_m[b:b + 1], o["im"]) and torch.equal(fps_o[b:b + 1], o["io"]), tag + "FPS indices"
+            att = ca["atten"][b:b + 1]
+            worst["att"] = max(worst["att"], _d(att, o["coarse"]["atten"]))
+            assert _d(att, o["coarse"]["atten"]) <= 1e-4, tag + "coarse attention off by %.2e" % _d(att, o["coarse"]["atten"])
+            # (2) the oracle's sampling weights of the GPU's attention; thresholds up to 1e-6
+            w_o, w1_o = O.coarse_sampling_weights(att)
+            assert torch.equal(w1_o, ca["w1"][b:b + 1]), tag + "foreground mask differs"
+            cum = torch.cumsum(w_o, dim=1)
+            cum = (cum / (cum[:, -1].unsqueeze(1) + 1e-8))[0].double()
+            u = o["rand"][0].double()
+            gi = ca["idx"][b].long()
+            eps = 1e-6
+            ok_hi = cum[gi] >= u - eps
+            ok_lo = (gi == 0) | (cum[(gi - 1).clamp(min=0)] < u + eps)
+            none = u > cum[-1] - eps  # no cumulative weight reaches u: the reference's argmax of an all-false row is 0
+            valid = (ok_hi & ok_lo) | (none & (gi == 0))
+            assert bool(valid.all()), tag + "%d sampled indices are not first-(cum >= u) indices" % int((~valid).sum())
+            n_idx_diff += int((gi != o["coarse"]["idx"][0]).sum())
+            # (3) the oracle from the GPU's samples
+            Rs_o, ts_o, dis_o = O.coarse_hypotheses(gi.unsqueeze(0), o["spm"], o["spo"], n1)
+            R0o, t0o, top_o, sc_o = O.coarse_select(Rs_o, ts_o, dis_o, w1_o, o["spm"], o["mp"], cfg["nproposal2"])
+            if max(_d(R0c[b:b + 1], R0o), _d(t0c[b:b + 1], t0o)) > 1e-4:
+                h = int(ca["best"][b])
+                pos = (top_o[0] == h).nonzero()
+                assert pos.numel() == 1, tag + "the GPU's coarse pick (hypothesis %d) is not among the oracle's 300 candidates" % h
+                rel = float((sc_o[0].max() - sc_o[0, pos[0, 0]]) / sc_o[0].max())
+                assert rel < 1e-6, tag + "coarse pick differs and is no tie: the oracle scores it %.3e (relative) below its best" % rel
+                assert max(_d(R0c[b:b + 1], Rs_o[:, h]), _d(t0c[b:b + 1], ts_o[:, h, 0])) <= 1e-4, tag + "coarse pick: pose of hypothesis"
+                n_tie += 1
+            # (4) fine stage given the GPU's coarse pose
+            same = max(_d(R0c[b:b + 1], o["R0"]), _d(t0c[b:b + 1], o["t0"])) <= 1e-5
+            if same:
+                Rf, tf, sf = o["R"], o["t"], o["s"]
+                n_e2e_same += 1
+            else:
+                Rf, tf, sf = o["fine"](R0c[b:b + 1], t0c[b:b + 1])
+            dfin = max(_d(Rc[b:b + 1], Rf), _d(tc[b:b + 1], tf), _d(sc[b:b + 1], sf))
+            worst["fine_given_pose"] = max(worst["fine_given_pose"], dfin)
+            assert dfin <= 1e-4, tag + "final pose / score given the coarse pose off by %.2e (same coarse choice: %s)" % (dfin, same)
+            if same:
+                worst["e2e"] = max(worst["e2e"], dfin)
+    # (5) the GPU's fine stage from the oracle's coarse pose, all 32 in one call
+    init = (torch.cat(oR0).to(dev), torch.cat(ot0).to(dev))
+    R5, t5, s5 = pem.pem_match(*[d[k] for k in keys], W, d["rand"], init_pose=init)
+    torch.cuda.synchronize()
+    d5 = max(_close(R5, torch.cat(oR), 1e-4, "R from the oracle's coarse pose"), _close(t5, torch.cat(ot), 1e-4, "t from the oracle's coarse pose"),
+             _close(s5, torch.cat(os_), 1e-4, "score from the oracle's coarse pose"))
+    print("\nconfig 2, B = 32: %d of 32 proposals make the oracle's coarse choice (end to end max diff %.2e); %d sampled indices of %d "
+          "differ (all within 1e-6 of their threshold); %d asserted score ties; coarse attention max diff %.2e; fine stage given the "
+          "GPU's pose %.2e, given the oracle's pose %.2e" % (n_e2e_same, worst["e2e"], n_idx_diff, B * 3 * n1, n_tie, worst["att"],
+                                                             worst["fine_given_pose"], d5))
 
 
 # ------------------------------------------------------------------------------------------------------- config 4

@@ -482,6 +482,31 @@ def test_gemm_operand_range(dev, sa, sw):
     assert err < 4e-6 * scale, "relative error %.2e of the result scale" % (err / scale)
 
 
+# --------------------------------------------------------------------------------------------------- a6: pairwise_distance
+def test_pairwise_distance_golden_bit_exact(dev):
+    """SURVEY 8a row a6 directly: the device recipe of pairwise_distance (PEM/utils/model_utils.py:101-128) against the reference's
+    own outputs in tests/golden/pairwise.npz -- the 197-point sparse cloud with the (100,100,100) bg point (the geometric embedding's
+    use) and 196 x 1024 (the hypothesis scoring's use; full SHA-256 of all three batches + the first 16 rows) -- bit for bit, through
+    the C ABI (sam6d_pairwise_distance) and through the drop-in model_utils.pairwise_distance."""
+    import hashlib
+    import model_utils as MU
+    from sam6d_hip import pem
+    g = golden("pairwise")
+    pts = _t(g["pts"]).to(dev)
+    pd = pem.pairwise_distance(pts, pts)
+    assert np.array_equal(pd.cpu().numpy(), g["pd"]), "pairwise_distance 197 x 197 (incl. the bg point): %d entries differ" % int(
+        (pd.cpu().numpy() != g["pd"]).sum())
+    a, b = _t(g["a"]).to(dev), _t(g["b"]).to(dev)
+    pd2 = MU.pairwise_distance(a, b)
+    assert np.array_equal(pd2[0, :16].cpu().numpy(), g["pd2_b0"])
+    assert hashlib.sha256(np.ascontiguousarray(pd2.cpu().numpy()).tobytes()).hexdigest() == str(g["pd2_sha"])
+    # channel-first form of the same call
+    pd3 = MU.pairwise_distance(a.transpose(1, 2), b.transpose(1, 2), channel_first=True)
+    assert torch.equal(pd3, pd2)
+    # the diagonal is NOT exactly zero in this recipe (SURVEY 8c n2) -- and must not be "fixed"
+    assert float(pd.diagonal(dim1=1, dim2=2).abs().max()) > 0
+
+
 # --------------------------------------------------------------------------------------------------- end to end
 def _to(dev, inp):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
@@ -493,16 +518,24 @@ def _rot_deg(Ra, Rb):
     return torch.rad2deg(torch.acos(c))
 
 
+@pytest.mark.parametrize("kernels", ["default", "materialised"])
 @pytest.mark.parametrize("tag", ["kat", "cfg2"])
-def test_pem_end_to_end_vs_reference(dev, W, tag):
-    """Whole path at the post-feature-extraction seam vs the reference's outputs (tests/golden/pem_e2e.npz, B=2)."""
+def test_pem_end_to_end_vs_reference(dev, W, tag, kernels):
+    """Whole path at the post-feature-extraction seam vs the reference's outputs (tests/golden/pem_e2e.npz, B=2): with the DEFAULT
+    kernels (fused RPE attention without the embedding tensor + the fine-match pipeline; return_aux does not change the kernel choice)
+    and with the materialised launch-per-op forms (embedding tensor, (B,2049,2049) attention matrix)."""
     from sam6d_hip import pem, synth
     g = golden("pem_e2e")
     inp = synth.kat_inputs(B=2, seed=int(g["kat_seed"])) if tag == "kat" else synth.config2_inputs(B=2, seed=int(g["cfg2_seed"]))
     d = _to(dev, inp)
+    cfg = pem.DEFAULT_CFG if kernels == "default" else dict(pem.DEFAULT_CFG, fused_rpe=False, fused_fine=False)
     R, t, s, aux = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W,
-                                 d["rand"], return_aux=True)
+                                 d["rand"], cfg=cfg, return_aux=True)
     torch.cuda.synchronize()
+    from sam6d_hip import _lib
+    if _lib.load().sam6d_get_matmul_mode() >= 1:
+        assert isinstance(aux["geo"], pem.GeoContext) == (kernels == "default"), "the fused RPE path must be what `default` runs"
+        assert ("atten" in aux["fine"]) == (kernels != "default"), "the fine-match pipeline must be what `default` runs"
     assert np.array_equal(aux["fps_idx_m"].cpu().numpy().astype(np.int16), g[tag + "_fps_m"])
     assert np.array_equal(aux["fps_idx_o"].cpu().numpy().astype(np.int16), g[tag + "_fps_o"])
     dR0 = _rot_deg(aux["init_R"], _t(g[tag + "_R0"]))
@@ -645,18 +678,39 @@ def test_rpe_fused_query_magnitudes(dev, W, xs):
 
 def test_rpe_fused_range_guard(dev, sd):
     """Weights whose projected angular embedding could leave the fp16 range of the score kernel's second contraction are detected on
-    the host (sum of |Chebyshev coefficients| per channel) and keep the materialised-embedding path."""
-    from sam6d_hip import pem
+    the host (sum of |Chebyshev coefficients| per channel) and keep the materialised-embedding path; weights whose x1024 images would
+    overflow fp16 altogether take the exact fp32 embedding kernel.  Every routed result is checked against matmul mode 0."""
+    from sam6d_hip import _lib, pem
     W1 = pem.PemWeights(sd, dev)
-    assert pem.fused_rpe_in_range(W1)
-    big = dict(sd)
+    assert pem.fused_rpe_in_range(W1) and pem.geo_images_in_range(W1)
     key = [k for k in sd if k.endswith("geometric_structure_embedding.proj_a.weight") or k.endswith("proj_a.weight")][0]
-    big[key] = sd[key] * 4000.0
-    W2 = pem.PemWeights(big, dev)
-    assert not pem.fused_rpe_in_range(W2)
-    pts = torch.rand(1, 32, 3).to(dev)
-    with pytest.raises(ValueError):
-        pem.geo_context(pts, W2)
+    keyd = key.replace("proj_a", "proj_d")
+    pts = torch.rand(2, 40, 3, generator=torch.Generator().manual_seed(3))
+    pts[:, 0] = 100.0  # the bg point: indices far outside the Chebyshev range
+    pts = pts.to(dev)
+    seen = set()
+    prev = _lib.load().sam6d_get_matmul_mode()
+    for which, scale in ((key, 20.0), (key, 150.0), (key, 4000.0), (keyd, 20.0), (keyd, 4000.0)):
+        big = dict(sd)
+        big[which] = sd[which] * scale
+        W2 = pem.PemWeights(big, dev)
+        fits_fused, fits_img = pem.fused_rpe_in_range(W2), pem.geo_images_in_range(W2)
+        seen.add((fits_fused, fits_img))
+        if not fits_fused:
+            with pytest.raises(ValueError):
+                pem.geo_context(pts, W2)
+        got = pem.geo_embedding(pts, W2)
+        try:
+            _lib.call("sam6d_set_matmul_mode", 0)
+            want = pem.geo_embedding(pts, W2)
+        finally:
+            _lib.call("sam6d_set_matmul_mode", prev)
+        assert torch.isfinite(got).all(), "scale %g: non-finite embedding (fp16 image overflow)" % scale
+        sc = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * sc, "scale %g (fused ok %s, images ok %s): %.3e of %.3e" % (scale, fits_fused, fits_img, err, sc)
+    if prev >= 1:
+        assert (False, True) in seen and (False, False) in seen, "the scales no longer exercise both guards: %s" % seen
 
 
 def test_pem_match_fused_vs_materialised(dev, W):
