@@ -54,6 +54,13 @@ int sam6d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M
  * idx1 (B,M,nsample1), idx2 (B,M,nsample2), each identical to the single-radius call. */
 int sam6d_ball_query2(const float* new_xyz, const float* xyz, int B, int N, int M, float radius1, int nsample1, int* idx1,
                       float radius2, int nsample2, int* idx2, void* stream);
+/* sam6d_ball_query2 with spatial pruning (same call site, PEM/model/fine_point_matching.py:108-131; semantics EXT/src/ball_query.cpp:16-62,
+ * identical outputs): the cloud is bucketed into a uniform grid first and a query only tests the points of the 27 cells around it;
+ * the first-nsample-in-index-order rule is kept by collecting hits in a per-query bit mask.  ws: sam6d_ball_query2_grid_workspace_bytes(B, N)
+ * bytes of scratch, 16-byte aligned.  N > 8192 falls back to the all-pairs scan. */
+size_t sam6d_ball_query2_grid_workspace_bytes(int B, int N);
+int sam6d_ball_query2_grid(const float* new_xyz, const float* xyz, int B, int N, int M, float radius1, int nsample1, int* idx1,
+                           float radius2, int nsample2, int* idx2, void* ws, size_t ws_bytes, void* stream);
 
 /* replaces `at::Tensor group_points(at::Tensor points, at::Tensor idx)` (EXT/src/group_points.cpp:79-108; loop :20-45).
  * points (B,C,N) f32, idx (B,M,S) i32 -> out (B,C,M,S) f32. */
@@ -217,6 +224,14 @@ int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n
  * AttentionLayer.linear.  n <= 256, m <= 208. */
 int sam6d_cross_attention(const float* x, const float* kv, const void* wq_image, const float* bq, float inv_wq_scale, float* out,
                           int B, int n, int m, void* stream);
+/* sam6d_cross_attention with the key-side projection inside as well (MultiHeadAttention.forward, PEM/model/transformer.py:127-129:
+ * proj_k / proj_v of the memory tokens): mem (B,m,256) the memory tokens; wkv_image (sam6d_cross_attention_kv_image_bytes() bytes) =
+ * per head h the sam6d_pack_panels images of proj_k.weight rows 64h..64h+64 then proj_v.weight rows 64h..64h+64 (K = 256, ksteps 8,
+ * one common pack scale, inv_wkv_scale its inverse); bkv (512) = proj_k.bias | proj_v.bias.  k and v never reach HBM. */
+long sam6d_cross_attention_kv_image_bytes(void);
+int sam6d_cross_attention_kv(const float* x, const float* mem, const void* wq_image, const float* bq, float inv_wq_scale,
+                             const void* wkv_image, const float* bkv, float inv_wkv_scale, float* out, int B, int n, int m,
+                             void* stream);
 
 /* replaces MultiHeadAttention.forward / RPEMultiHeadAttention.forward core (PEM/model/transformer.py:131-148,395-418):
  * 4 heads x 64, softmax((q.k [+ qp.E]) / 8) v.  q (B,n,256) ldq/sq; k,v (B,m,256); out (B,n,256).
@@ -224,6 +239,14 @@ int sam6d_cross_attention(const float* x, const float* kv, const void* wq_image,
 int sam6d_attention(const float* q, const float* k, const float* v, const float* qp, const float* E, float* out, int B,
                     int n, int m, long ldq, long ldk, long ldv, long ldo, long sq, long sk, long sv, long so,
                     void* stream);
+/* Stand-alone pieces for callers of a single attention sub-module (the fused kernels never materialise the probabilities):
+ * sam6d_scaled_softmax: out[r][0..n) = softmax_m((a[r][m] + b[r][m]) * scale), b may be NULL -- the softmax of MultiHeadAttention.forward
+ *   (PEM/model/transformer.py:134-143) and, with b = the q . proj_p(E) term, of RPEMultiHeadAttention.forward (:404-412).
+ * sam6d_sinusoid_embed: SinusoidalPositionalEmbedding.forward (PEM/model/transformer.py:269-285): x (n) -> out (n, d_model),
+ *   out[i][2j] = sin(x_i div_term_j), out[i][2j+1] = cos(x_i div_term_j). */
+int sam6d_scaled_softmax(const float* a, const float* b, float scale, long rows, int n, long lda, long ldb, float* out, long ldo,
+                         void* stream);
+int sam6d_sinusoid_embed(const float* x, long n, const float* div_term, int d_model, float* out, void* stream);
 
 /* LinearAttention.forward pieces (PEM/model/transformer.py:546-578, kv path :569-572). */
 int sam6d_linattn_focus_k(float* k, const float* scale, long rows, long ld, void* stream);
@@ -288,6 +311,13 @@ int sam6d_select_smallest(const float* dis, int B, int n, int k, int* sel, void*
 int sam6d_score_select_hypotheses(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,
                                   const float* model, const float* radius, int B, int N1, int P, int nh, int k,
                                   float* scores, float* R, float* t, int* best, void* stream);
+/* The same scoring + arg-max (PEM/utils/model_utils.py:258-275; the distance contraction is the reference's own torch.matmul,
+ * :117) with the K = 3 products on the fp32 matrix cores -- identical distance bits -- and the weighted distances staged in `ws`
+ * (sam6d_score_select_workspace_bytes(B, N1, k) bytes), summed per hypothesis in a fixed order.  P <= 4096. */
+size_t sam6d_score_select_workspace_bytes(int B, int N1, int k);
+int sam6d_score_select_hypotheses_ws(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,
+                                     const float* model, const float* radius, int B, int N1, int P, int nh, int k, float* scores,
+                                     float* R, float* t, int* best, float* ws, size_t ws_bytes, void* stream);
 /* Fine-stage similarity + soft assignment as one pipeline (csrc/finematch.hip): compute_feature_similarity
  * (PEM/utils/model_utils.py:131-153: F.normalize both sides, f1 f2^T / temp) followed by the head of compute_fine_Rt (:308-331: the
  * two softmaxes, both arg-max label vectors, the masked assignment's row sums and weighted targets) without materialising the
@@ -327,6 +357,16 @@ int sam6d_ism_semantic(const float* scores, int Nq, int No, int Nt, int mode, fl
 /* replaces compute_straight + compute_visible_ratio reductions (ISM/model/loss.py:52-76) over sim (Ns,P,P). */
 int sam6d_ism_patch_scores(const float* sim, const float* q_appe, int Ns, int P, int D, float thred, float* appe, float* vis,
                            void* stream);
+/* compute_appearance_score + compute_visible_ratio (ISM/model/detector.py:298-308, 310-322; ISM/model/loss.py:52-76) WITHOUT the
+ * (Ns,P,P) similarity tensor and without gathering the chosen templates' descriptors: proposal p multiplies query patches
+ * q[qsel ? qsel[p] : p] (P,D) with ref[obj[p]][best[p]] (P,D) read in place (ref: (No,Nt,P,D)); the tile epilogue keeps row / column
+ * maxima only.  sam6d_ism_patch_fused fills the workspace (sam6d_ism_patch_fused_workspace_bytes(Ns, P) bytes), sam6d_ism_patch_fused_scores
+ * turns it into appe (Ns) and / or vis (Ns) for a threshold (either output may be NULL).  Descriptors must be L2-normalised rows
+ * (|x| <= 1, as ISM/model/dinov2.py:322-324 produces them; masked patches all-zero); P a multiple of 128, D of 32; indices int64. */
+size_t sam6d_ism_patch_fused_workspace_bytes(int Ns, int P);
+int sam6d_ism_patch_fused(const float* q, const long long* qsel, const float* ref, const long long* obj, const long long* best, int Ns,
+                          int Nt, int P, int D, void* ws, size_t ws_bytes, void* stream);
+int sam6d_ism_patch_fused_scores(const void* ws, int Ns, int P, float thred, float* appe, float* vis, void* stream);
 /* replaces project_template_to_image + Calculate_the_query_translation (ISM/model/detector.py:209-246,
  * ISM/utils/trimesh_utils.py:77-105): masks (Ns,H,W) f32, depth (H,W) i32, K (3,3) f64, poses (Nt,4,4) f32,
  * pointcloud (No,Npc,3) -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3); part_ws (Ns*64*4) f64 scratch. */

@@ -217,3 +217,60 @@ extern "C" int sam6d_attention(const float* q, const float* k, const float* v, c
                        ldk, ldv, ldo, sq, sk, sv, so, scale);
   SAM6D_LAUNCH_CHECK("attention");
 }
+
+// =========================================================================================================
+// Stand-alone pieces of the attention modules for callers that use a sub-module directly (the drop-in forwards of
+// pem/transformer.py; the fused kernels above / in rpe.hip / xattn.hip never materialise the probabilities):
+//   scaled_softmax:  out[r][0..n) = softmax_m((a[r][m] + b[r][m]) * scale)     (MultiHeadAttention.forward, PEM/model/transformer.py:134-143;
+//                    with b = the q . proj_p(E) term: RPEMultiHeadAttention.forward :404-412)
+//   sinusoid_embed:  out[i][2 j], out[i][2 j + 1] = sin(x_i w_j), cos(x_i w_j)   (SinusoidalPositionalEmbedding.forward :269-285)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void scaled_softmax_kernel(const float* __restrict__ a, const float* __restrict__ b, float scale,
+                                                             long rows, int n, long lda, long ldb, float* __restrict__ out, long ldo) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* ar = a + r * lda;
+  const float* br = b ? b + r * ldb : nullptr;
+  float mx = -INFINITY;
+  for (int m = lane; m < n; m += 64) mx = fmaxf(mx, (ar[m] + (br ? br[m] : 0.f)) * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int m = lane; m < n; m += 64) sum += expf((ar[m] + (br ? br[m] : 0.f)) * scale - mx);
+  sum = wave_sum(sum);
+  float* o = out + r * ldo;
+  for (int m = lane; m < n; m += 64) o[m] = expf((ar[m] + (br ? br[m] : 0.f)) * scale - mx) / sum;
+}
+
+extern "C" int sam6d_scaled_softmax(const float* a, const float* b, float scale, long rows, int n, long lda, long ldb, float* out,
+                                    long ldo, void* stream) {
+  SAM6D_REQUIRE(a && out && rows >= 0 && n > 0 && lda >= n && ldo >= n && (!b || ldb >= n), "scaled_softmax: bad arguments");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(scaled_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, scale, rows, n,
+                     lda, ldb, out, ldo);
+  SAM6D_LAUNCH_CHECK("scaled_softmax");
+}
+
+__global__ __launch_bounds__(256) void sinusoid_embed_kernel(const float* __restrict__ x, long n, const float* __restrict__ div_term,
+                                                             int half, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * half) return;
+  const long i = e / half;
+  const int j = (int)(e - i * half);
+  const float w = x[i] * div_term[j];  // the fp32 product the reference forms (transformer.py:278)
+  // sin / cos of that fp32 value in double, rounded once: the device's fp32 sincosf is only good to ~0.3 ulp OF THE ARGUMENT (2e-5 at
+  // w ~ 866, the bg point's distance index), torch's CPU sin / cos to ~1 ulp of the result
+  double sn, cs;
+  sincos((double)w, &sn, &cs);
+  out[(i * half + j) * 2] = (float)sn;
+  out[(i * half + j) * 2 + 1] = (float)cs;
+}
+
+extern "C" int sam6d_sinusoid_embed(const float* x, long n, const float* div_term, int d_model, float* out, void* stream) {
+  SAM6D_REQUIRE(x && div_term && out && n >= 0 && d_model > 0 && (d_model & 1) == 0, "sinusoid_embed: bad arguments (even d_model)");
+  if (n == 0) return 0;
+  const int half = d_model / 2;
+  hipLaunchKernelGGL(sinusoid_embed_kernel, dim3((unsigned)((n * half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, div_term,
+                     half, out);
+  SAM6D_LAUNCH_CHECK("sinusoid_embed");
+}

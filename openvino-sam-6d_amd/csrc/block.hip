@@ -751,6 +751,11 @@ struct RfArgs {
   int n, ldp;                //   then the v third of qkv is not written
 };
 
+// VT: the values go to vT (8 scattered 4-byte stores per value panel) instead of the v third of qkv (2 float4 stores).
+// Stores are issued for every lane -- rows past M are clamped to row M - 1 and rewrite its values -- so that the number of vector-memory
+// operations between two panel DMAs is a compile-time constant: the wait at the head of a panel then lets the previous panel's STORES
+// stay in flight (s_waitcnt vmcnt(#stores)) instead of draining them (vmcnt(0) cost a store round trip per panel: 36 per workgroup).
+template <bool VT>
 __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* pan = lds;  // 2 x TB_PANEL_BYTES
@@ -779,9 +784,11 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
       }
     }
   };
-  auto next_panel = [&](auto IC) -> unsigned {
+  // panel I's DMA was issued at the head of panel I - 1; younger than it are only the NST stores of panel I - 1's epilogue
+  auto next_panel = [&](auto IC, auto NSTC) -> unsigned {
     constexpr int I = decltype(IC)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int NST = decltype(NSTC)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     __syncthreads();
     dma(std::integral_constant<int, I + 1>{});
     return pan_lds + (I & 1) * TB_PANEL_BYTES;
@@ -827,15 +834,17 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
   float* orow = a.qkv + (size_t)row * 768;
   tb_static_for<0, 24>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    const unsigned p = next_panel(std::integral_constant<int, j>{});
+    // stores of the previous panel: none before panel 0 (the wait also covers the x rows), 8 after a transposed value panel, else 2
+    constexpr int prev_st = j == 0 ? 0 : ((VT && j - 1 >= 16) ? 8 : 2);
+    const unsigned p = next_panel(std::integral_constant<int, j>{}, std::integral_constant<int, prev_st>{});
     f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
     tb_mma<8>(c0, c1, p, xh, xl, fr, fg, false);
     const float4 b0 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 4 * fg);
     const float4 b1 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 16 + 4 * fg);
     c0 = f32x4{c0[0] * inv0 + b0.x, c0[1] * inv0 + b0.y, c0[2] * inv0 + b0.z, c0[3] * inv0 + b0.w};
     c1 = f32x4{c1[0] * inv0 + b1.x, c1[1] * inv0 + b1.y, c1[2] * inv0 + b1.z, c1[3] * inv0 + b1.w};
-    if (valid) {
-      if (j >= 16 && a.vT) {  // v channel c of token tok of its cloud -> vT[cloud][c][tok]: 16 consecutive tokens per lane group
+    {
+      if constexpr (VT && j >= 16) {  // v channel c of token tok of its cloud -> vT[cloud][c][tok]: 16 consecutive tokens per lane group
         float* vt = a.vT + (size_t)(row / a.n) * 256 * a.ldp + (row % a.n);
         const int cb = 32 * (j - 16) + 4 * fg;
 #pragma unroll
@@ -862,7 +871,9 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
     f32x4 pa[16];
     tb_static_for<0, 2>([&](auto GG) {
       constexpr int gq = decltype(GG)::value;
-      const unsigned p4 = next_panel(std::integral_constant<int, 24 + 3 * h + gq>{});
+      // younger than this unit's DMA: the last qkv panel's stores (h = 0), the 2 qd stores of the previous head, or nothing (gq = 1)
+      constexpr int prev_st = gq == 1 ? 0 : (h == 0 ? (VT ? 8 : 2) : 2);
+      const unsigned p4 = next_panel(std::integral_constant<int, 24 + 3 * h + gq>{}, std::integral_constant<int, prev_st>{});
       tb_static_for<0, 4>([&](auto U) {
         constexpr int j = 4 * gq + decltype(U)::value;
         f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -871,17 +882,17 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
         pa[2 * j + 1] = f32x4{c1[0] * inv1, c1[1] * inv1, c1[2] * inv1, c1[3] * inv1};
       });
     });
-    if (valid) {
+    {
       float* o = a.qp + (size_t)row * 1024 + 256 * h;
 #pragma unroll
       for (int i = 0; i < 16; ++i) *reinterpret_cast<float4*>(o + 16 * i + 4 * fg) = make_float4(pa[i][0], pa[i][1], pa[i][2], pa[i][3]);
     }
     half8 ph[8], pl[8];
     const float sp = tb_split_rows<16>(pa, ph, pl);
-    const unsigned p = next_panel(std::integral_constant<int, 24 + 3 * h + 2>{});
+    const unsigned p = next_panel(std::integral_constant<int, 24 + 3 * h + 2>{}, std::integral_constant<int, 16>{});  // the 16 qp stores
     f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
     tb_mma<8>(c0, c1, p, ph, pl, fr, fg, false);
-    if (valid) {
+    {
       const float inv2 = a.inv_dc * (1.0f / sp);
       float* o = a.qd + ((size_t)row * 4 + h) * 32;
       *reinterpret_cast<float4*>(o + 4 * fg) = make_float4(c0[0] * inv2, c0[1] * inv2, c0[2] * inv2, c0[3] * inv2);
@@ -911,7 +922,8 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
   if (M == 0) return 0;
   static unsigned long long done = 0;
   if (sam6d_first_use_on_device(&done)) {
-    hipError_t e = hipFuncSetAttribute((const void*)rpe_front_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)rpe_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rpe_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
     if (e != hipSuccess) {
       sam6d_set_error("rpe_front: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -919,7 +931,10 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
     sam6d_setup_done_on_device(&done);
   }
   RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc, vT, n, ldp};
-  hipLaunchKernelGGL(rpe_front_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  if (vT)
+    hipLaunchKernelGGL(rpe_front_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(rpe_front_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("rpe_front");
 }
 

@@ -24,6 +24,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float fm_f4 __attribute__((ext_vector_type(4)));
 
 #define FM_C 256          // channels
 #define FM_COL0 3         // physical column of logical column 0
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict_
     for (int it = 0; it < NP; ++it) {
       const int rr = it * RPP + rr0;
       const int nn = 1 + nrow0 + wm + 32 * i + rr, mm = 1 + mcol0 + wn + c4;
-      *reinterpret_cast<float4*>(Eb + (size_t)nn * lde + mm) = *reinterpret_cast<const float4*>(&slab[rr * SLD + c4]);
+      // non-temporal: E (537 MB per step) is read back only by the label / assignment passes, long after it has left the L2 -- kept out
+      // of the cache it stops evicting the GEMM operands (4 MB per proposal = one XCD's L2) the neighbouring tiles are about to re-read
+      __builtin_nontemporal_store(*reinterpret_cast<const fm_f4*>(&slab[rr * SLD + c4]), reinterpret_cast<fm_f4*>(Eb + (size_t)nn * lde + mm));
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -307,7 +310,10 @@ __global__ __launch_bounds__(256) void fm_labels_kernel(const float* __restrict_
     const float* er = Eb + (size_t)nn * lde;
     float4 e[8];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) e[g] = *reinterpret_cast<const float4*>(er + 1 + 4 * (lane + 64 * g));
+    for (int g = 0; g < 8; ++g) {
+      const fm_f4 x = __builtin_nontemporal_load(reinterpret_cast<const fm_f4*>(er + 1 + 4 * (lane + 64 * g)));  // streamed once
+      e[g] = make_float4(x[0], x[1], x[2], x[3]);
+    }
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     if (lane == 0 && chunk == 0) {  // the bg column: a candidate of the row arg-max only
@@ -440,7 +446,10 @@ __global__ __launch_bounds__(256) void fm_assign_kernel(const float* __restrict_
       const float* er = Eb + (size_t)nn * lde;
       float4 e[8];
 #pragma unroll
-      for (int g = 0; g < 8; ++g) e[g] = *reinterpret_cast<const float4*>(er + 1 + 4 * (lane + 64 * g));
+      for (int g = 0; g < 8; ++g) {
+      const fm_f4 x = __builtin_nontemporal_load(reinterpret_cast<const fm_f4*>(er + 1 + 4 * (lane + 64 * g)));  // streamed once
+      e[g] = make_float4(x[0], x[1], x[2], x[3]);
+    }
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const float ev[4] = {e[g].x, e[g].y, e[g].z, e[g].w};

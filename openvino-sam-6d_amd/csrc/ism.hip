@@ -219,6 +219,208 @@ extern "C" int sam6d_ism_patch_scores(const float* sim, const float* q_appe, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same two scores WITHOUT the similarity tensor and without gathering the chosen templates' descriptors ("fuse"):
+// proposal p multiplies its P x D query patches with the P x D patches of template (obj[p], best[p]) read IN PLACE from ref_data
+// (detector.py:298-308, 310-322 gather them into a new tensor first), on v_mfma_f32_32x32x16_f16 with the fp16 x3 split done while
+// the tiles are staged (descriptors are L2-normalised, |x| <= 1: x 2^10, split, products exact in the fp32 accumulator).  The 128 x 128
+// tile never leaves the registers: the epilogue reduces it to row maxima over its 64-column wave slice and column maxima over its
+// 64-row slice (4 partials per row / column for P = 256) plus the query-patch occupancy flags; ism_patch_finish_kernel merges them in
+// the summation order of ism_patch_scores_kernel, so both paths return the same bits given the same products.
+// (N, 256, 256) floats = 39 MB written + read and 2 x 157 MB of gathered descriptors per pass disappear.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float ip_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 ip_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ip_half4 __attribute__((ext_vector_type(4)));
+typedef unsigned ip_u2 __attribute__((ext_vector_type(2)));
+#define IP_BK 32
+#define IP_LD 40
+#define IP_SCALE 1024.0f
+__device__ __forceinline__ void ip_split4(const float4 v, ip_half4& hi, ip_half4& lo) {
+  unsigned h0, h1, l0, l1;
+  sam6d_split2_f16(v.x * IP_SCALE, v.y * IP_SCALE, h0, l0);
+  sam6d_split2_f16(v.z * IP_SCALE, v.w * IP_SCALE, h1, l1);
+  hi = __builtin_bit_cast(ip_half4, ip_u2{h0, h1});
+  lo = __builtin_bit_cast(ip_half4, ip_u2{l0, l1});
+}
+
+__global__ __launch_bounds__(256) void ism_patch_fused_kernel(const float* __restrict__ q, const long long* __restrict__ qsel,
+                                                              const float* __restrict__ ref, const long long* __restrict__ obj,
+                                                              const long long* __restrict__ best, int Nt, int P, int D,
+                                                              float* __restrict__ rowpart, float* __restrict__ colpart,
+                                                              float* __restrict__ nzflag) {
+  __shared__ __attribute__((aligned(16))) _Float16 smem[4 * 128 * IP_LD];
+  _Float16* Ah = smem;
+  _Float16* Al = Ah + 128 * IP_LD;
+  _Float16* Bh = Al + 128 * IP_LD;
+  _Float16* Bl = Bh + 128 * IP_LD;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int p = blockIdx.y, nt = P / 128, tm = blockIdx.x % nt, tn = blockIdx.x / nt, slots = 2 * nt;
+  const float* A = q + ((size_t)(qsel ? qsel[p] : p) * P + 128 * tm) * D;
+  const float* W = ref + (((size_t)obj[p] * Nt + (size_t)best[p]) * P + 128 * tn) * D;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  ip_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sr = t >> 3, sk = (t & 7) * 4;
+  float4 va[4], vb[4];
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      va[u] = *reinterpret_cast<const float4*>(A + (size_t)(sr + 32 * u) * D + k0 + sk);
+      vb[u] = *reinterpret_cast<const float4*>(W + (size_t)(sr + 32 * u) * D + k0 + sk);
+    }
+  };
+  const int fr = lane & 31, fk = lane >> 5;
+  fetch(0);
+  for (int k0 = 0; k0 < D; k0 += IP_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ip_half4 hi, lo;
+      ip_split4(va[u], hi, lo);
+      *reinterpret_cast<ip_half4*>(&Ah[(sr + 32 * u) * IP_LD + sk]) = hi;
+      *reinterpret_cast<ip_half4*>(&Al[(sr + 32 * u) * IP_LD + sk]) = lo;
+      rs[u] += (va[u].x + va[u].y) + (va[u].z + va[u].w);
+      ip_split4(vb[u], hi, lo);
+      *reinterpret_cast<ip_half4*>(&Bh[(sr + 32 * u) * IP_LD + sk]) = hi;
+      *reinterpret_cast<ip_half4*>(&Bl[(sr + 32 * u) * IP_LD + sk]) = lo;
+    }
+    __syncthreads();
+    if (k0 + IP_BK < D) fetch(k0 + IP_BK);
+#pragma unroll
+    for (int ks = 0; ks < IP_BK; ks += 16) {
+      ip_half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const ip_half8*>(&Ah[(wm + 32 * i + fr) * IP_LD + ks + 8 * fk]);
+        al[i] = *reinterpret_cast<const ip_half8*>(&Al[(wm + 32 * i + fr) * IP_LD + ks + 8 * fk]);
+        bh[i] = *reinterpret_cast<const ip_half8*>(&Bh[(wn + 32 * i + fr) * IP_LD + ks + 8 * fk]);
+        bl[i] = *reinterpret_cast<const ip_half8*>(&Bl[(wn + 32 * i + fr) * IP_LD + ks + 8 * fk]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  const float un = 1.0f / (IP_SCALE * IP_SCALE);
+  // lane (fr, fk) holds rows (r & 3) + 8 (r >> 2) + 4 fk of column fr of each 32 x 32 tile
+  // ---- column maxima over this wave's 64 rows
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+    m = fmaxf(m, xor32_f32(m));
+    if (fk == 0) colpart[((size_t)p * P + 128 * tn + wn + 32 * j + fr) * slots + 2 * tm + (wave >> 1)] = m * un;
+  }
+  // ---- row maxima over this wave's 64 columns
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float m = fmaxf(acc[i][0][r], acc[i][1][r]);
+      m = row16_max_dpp(m);
+      m = fmaxf(m, xor16_f32(m));
+      if (fr == 0) rowpart[((size_t)p * P + 128 * tm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk) * slots + 2 * tn + (wave & 1)] = m * un;
+    }
+  // ---- occupancy of the query patches (count_nonzero(query.sum(-1)), loss.py:58): the workgroups of the first column tile
+  if (tn == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s_ = rs[u];
+      s_ += __shfl_xor(s_, 1, 64);
+      s_ += __shfl_xor(s_, 2, 64);
+      s_ += __shfl_xor(s_, 4, 64);
+      if ((t & 7) == 0) nzflag[(size_t)p * P + 128 * tm + sr + 32 * u] = (s_ != 0.f) ? 1.f : 0.f;
+    }
+  }
+}
+
+// merge: the summation order of ism_patch_scores_kernel (rows r = w, w + 4, ... per wave w; thread per column, wave sums)
+__global__ __launch_bounds__(256) void ism_patch_finish_kernel(const float* __restrict__ rowpart, const float* __restrict__ colpart,
+                                                               const float* __restrict__ nzflag, int P, int slots, float thr,
+                                                               float* __restrict__ appe, float* __restrict__ vis) {
+  __shared__ float red[3][4];
+  __shared__ float red2[4];
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float rsum = 0.f, nz = 0.f;
+  if (lane == 0) {
+    for (int r = wave; r < P; r += 4) {
+      float m = -INFINITY;
+      for (int s_ = 0; s_ < slots; ++s_) m = fmaxf(m, rowpart[((size_t)i * P + r) * slots + s_]);
+      rsum += m;
+      nz += nzflag[(size_t)i * P + r];
+    }
+  }
+  float cv = 0.f, cn = 0.f;
+  for (int c = t; c < P; c += 256) {
+    float m = -INFINITY;
+    for (int s_ = 0; s_ < slots; ++s_) m = fmaxf(m, colpart[((size_t)i * P + c) * slots + s_]);
+    cn += (m != 0.f) ? 1.f : 0.f;
+    cv += (m > thr && m != 0.f) ? 1.f : 0.f;
+  }
+  cv = wave_sum(cv);
+  cn = wave_sum(cn);
+  if (lane == 0) {
+    red[0][wave] = rsum;
+    red[1][wave] = nz;
+    red[2][wave] = cv;
+    red2[wave] = cn;
+  }
+  __syncthreads();
+  if (t == 0) {
+    const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float n = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float v = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float vn = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+    if (appe) appe[i] = fminf(fmaxf(a / (n + 1e-6f), 0.f), 1.f);
+    if (vis) vis[i] = v / (vn + 1e-6f);
+  }
+}
+
+extern "C" size_t sam6d_ism_patch_fused_workspace_bytes(int Ns, int P) { return (size_t)Ns * P * (2 * (P / 128) * 2 + 1) * 4; }
+
+extern "C" int sam6d_ism_patch_fused(const float* q, const long long* qsel, const float* ref, const long long* obj, const long long* best,
+                                     int Ns, int Nt, int P, int D, void* ws, size_t ws_bytes, void* stream) {
+  SAM6D_REQUIRE(q && ref && obj && best && ws && Ns >= 0 && Nt > 0, "ism_patch_fused: bad arguments");
+  SAM6D_REQUIRE(P > 0 && (P % 128) == 0 && D > 0 && (D % IP_BK) == 0, "ism_patch_fused: P must be a multiple of 128, D of 32");
+  SAM6D_REQUIRE(((((size_t)q) | ((size_t)ref) | ((size_t)ws)) & 15) == 0 && ws_bytes >= sam6d_ism_patch_fused_workspace_bytes(Ns, P),
+                "ism_patch_fused: 16-byte alignment / workspace size (sam6d_ism_patch_fused_workspace_bytes)");
+  if (Ns == 0) return 0;
+  const int nt = P / 128, slots = 2 * nt;
+  float* rowpart = (float*)ws;
+  float* colpart = rowpart + (size_t)Ns * P * slots;
+  float* nzflag = colpart + (size_t)Ns * P * slots;
+  hipLaunchKernelGGL(ism_patch_fused_kernel, dim3(nt * nt, Ns), dim3(256), 0, (hipStream_t)stream, q, qsel, ref, obj, best, Nt, P, D, rowpart,
+                     colpart, nzflag);
+  SAM6D_LAUNCH_CHECK("ism_patch_fused");
+}
+
+extern "C" int sam6d_ism_patch_fused_scores(const void* ws, int Ns, int P, float thred, float* appe, float* vis, void* stream) {
+  SAM6D_REQUIRE(ws && Ns >= 0 && P > 0 && (P % 128) == 0 && (appe || vis), "ism_patch_fused_scores: bad arguments");
+  if (Ns == 0) return 0;
+  const int slots = 2 * (P / 128);
+  const float* rowpart = (const float*)ws;
+  const float* colpart = rowpart + (size_t)Ns * P * slots;
+  const float* nzflag = colpart + (size_t)Ns * P * slots;
+  hipLaunchKernelGGL(ism_patch_finish_kernel, dim3(Ns), dim3(256), 0, (hipStream_t)stream, rowpart, colpart, nzflag, P, slots, thred, appe,
+                     vis);
+  SAM6D_LAUNCH_CHECK("ism_patch_fused_scores");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Query translation = mean back-projected masked depth (detector.py:234-246, trimesh_utils.py:77-105), then template
 // point cloud -> image (detector.py:209-232).  The reference's caller hands K and depth_scale over as float64
 // (ISM/run_inference_custom.py:87-94), which makes its whole translation computation float64 until the final

@@ -505,6 +505,203 @@ extern "C" int sam6d_ball_query2(const float* new_xyz, const float* xyz, int B, 
   SAM6D_LAUNCH_CHECK("ball_query2");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The two-radius ball query with spatial pruning -- same outputs, bit for bit (ball_query.cpp:16-62).
+// The all-pairs scan tests 2048 candidates per query to find ~70 hits.  Here the cloud is bucketed once into a G^3 grid of cells of
+// edge c = 1.001 max(r1, r2) (origin = the cloud's min corner, cell coordinates clamped to [0, G)): any point the fp32 test
+// d2 < r^2 accepts lies within +-1 cell of the query's cell in every axis (the 0.1 % margin covers the rounding of both the test and
+// the cell coordinates; clamping only merges cells).  A wave owns a query and scans the 9 (dy, dz) runs of up to 3 x-adjacent cells
+// (contiguous in the cell-sorted point list), 64 candidates per step: ~450 candidates instead of 2048 for a uniform unit cube.
+// The reference's result is the first `nsample` hits IN INDEX ORDER, and the grid visits candidates in cell order -- so hits only set
+// bit `index` of a per-query bit mask in LDS (ds_or_b32), and the ordered output is read off the mask afterwards: a prefix sum of the
+// words' popcounts over the wave gives every set bit its output slot.  The order inside a cell (the scatter uses LDS atomics) never
+// matters.  Workspace per cloud: N float4 (x, y, z, index) sorted by cell | G^3 + 1 cell starts | origin, 1 / c.
+// ---------------------------------------------------------------------------------------------------------
+#define BQG_G 16
+#define BQG_CELLS (BQG_G * BQG_G * BQG_G)
+#define BQG_MAXN 8192
+#define BQG_QPW 4            // queries per wave
+__host__ __device__ inline size_t bqg_cloud_bytes(int N) { return (size_t)N * 16 + (size_t)(BQG_CELLS + 1) * 4 + 12 + 16; }
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ int bqg_cell1(float v, float o, float inv_c) {
+  const float u = fminf(fmaxf((v - o) * inv_c, 0.0f), (float)(BQG_G - 1));  // (NaN -> 0)
+  return (int)u;
+}
+
+__global__ __launch_bounds__(1024) void bqg_build_kernel(const float* __restrict__ xyz, int N, float cell, unsigned char* __restrict__ ws) {
+  __shared__ int hist[BQG_CELLS];
+  __shared__ float red[3][16];
+  __shared__ int wsum[16];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* p = xyz + (size_t)b * N * 3;
+  unsigned char* wb = ws + (size_t)b * ((bqg_cloud_bytes(N) + 15) & ~(size_t)15);
+  float4* sorted = reinterpret_cast<float4*>(wb);
+  int* start = reinterpret_cast<int*>(wb + (size_t)N * 16);
+  float* org = reinterpret_cast<float*>(wb + (size_t)N * 16 + (size_t)(BQG_CELLS + 1) * 4);
+  float mx = INFINITY, my = INFINITY, mz = INFINITY;
+  for (int i = t; i < N; i += 1024) {
+    const float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    mx = fminf(mx, x); my = fminf(my, y); mz = fminf(mz, z);  // (fminf ignores NaN)
+  }
+  mx = wave_min(mx); my = wave_min(my); mz = wave_min(mz);
+  if (lane == 0) { red[0][wave] = mx; red[1][wave] = my; red[2][wave] = mz; }
+  for (int i = t; i < BQG_CELLS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  float ox = red[0][0], oy = red[1][0], oz = red[2][0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) { ox = fminf(ox, red[0][w]); oy = fminf(oy, red[1][w]); oz = fminf(oz, red[2][w]); }
+  if (!(ox > -3.0e38f && ox < 3.0e38f)) ox = 0.f;
+  if (!(oy > -3.0e38f && oy < 3.0e38f)) oy = 0.f;
+  if (!(oz > -3.0e38f && oz < 3.0e38f)) oz = 0.f;
+  const float inv_c = 1.0f / cell;
+  if (t == 0) { org[0] = ox; org[1] = oy; org[2] = oz; org[3] = inv_c; }
+  for (int i = t; i < N; i += 1024) {
+    const int c = (bqg_cell1(p[i * 3 + 2], oz, inv_c) * BQG_G + bqg_cell1(p[i * 3 + 1], oy, inv_c)) * BQG_G + bqg_cell1(p[i * 3], ox, inv_c);
+    atomicAdd(&hist[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 counts: 4 per thread, wave scan, wave totals
+  int v[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { v[u] = hist[t * 4 + u]; sum += v[u]; }
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int nb = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += nb;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int run = base + inc - sum;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    start[t * 4 + u] = run;
+    hist[t * 4 + u] = run;   // becomes the scatter cursor
+    run += v[u];
+  }
+  if (t == 1023) start[BQG_CELLS] = run;
+  __syncthreads();
+  for (int i = t; i < N; i += 1024) {
+    const float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    const int c = (bqg_cell1(z, oz, inv_c) * BQG_G + bqg_cell1(y, oy, inv_c)) * BQG_G + bqg_cell1(x, ox, inv_c);
+    const int slot = atomicAdd(&hist[c], 1);
+    sorted[slot] = make_float4(x, y, z, __int_as_float(i));
+  }
+}
+
+template <int WPL>  // mask words per lane: N <= 2048 * WPL
+__global__ __launch_bounds__(256) void bqg_query_kernel(const float* __restrict__ new_xyz, int N, int M, float r2a, int nsa,
+                                                        int* __restrict__ idxa, float r2b, int nsb, int* __restrict__ idxb,
+                                                        const unsigned char* __restrict__ ws) {
+  __shared__ unsigned maskA[4][64 * WPL];
+  __shared__ unsigned maskB[4][64 * WPL];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned char* wb = ws + (size_t)b * ((bqg_cloud_bytes(N) + 15) & ~(size_t)15);
+  const float4* sorted = reinterpret_cast<const float4*>(wb);
+  const int* start = reinterpret_cast<const int*>(wb + (size_t)N * 16);
+  const float* org = reinterpret_cast<const float*>(wb + (size_t)N * 16 + (size_t)(BQG_CELLS + 1) * 4);
+  const float ox = org[0], oy = org[1], oz = org[2], inv_c = org[3];
+  unsigned* mA = maskA[wave];
+  unsigned* mB = maskB[wave];
+  for (int qi = 0; qi < BQG_QPW; ++qi) {
+    const int q = (blockIdx.x * 4 + wave) * BQG_QPW + qi;
+    if (q >= M) break;  // (wave-uniform)
+    const float* qp = new_xyz + ((size_t)b * M + q) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) { mA[lane * WPL + j] = 0u; mB[lane * WPL + j] = 0u; }
+    const int cx = bqg_cell1(qx, ox, inv_c), cy = bqg_cell1(qy, oy, inv_c), cz = bqg_cell1(qz, oz, inv_c);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, BQG_G - 1);
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= BQG_G) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= BQG_G) continue;
+        const int row = (z * BQG_G + y) * BQG_G;
+        const int lo = start[row + x0], hi = start[row + x1 + 1];
+        for (int k = lo + lane; k < hi; k += 64) {
+          const float4 c = sorted[k];
+          const float d2 = (qx - c.x) * (qx - c.x) + (qy - c.y) * (qy - c.y) + (qz - c.z) * (qz - c.z);
+          const int id = __float_as_int(c.w);
+          if (d2 < r2b) atomicOr(&mB[id >> 5], 1u << (id & 31));
+          if (d2 < r2a) atomicOr(&mA[id >> 5], 1u << (id & 31));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's LDS atomics are ordered before the reads below
+    // ordered read-out of a mask: lane L owns words L*WPL .. L*WPL+WPL-1 (ascending indices)
+    auto emit = [&](const unsigned* m, int ns, int* out) {
+      unsigned w[WPL];
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) { w[j] = m[lane * WPL + j]; cnt += __popc(w[j]); }
+      int inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += nb;
+      }
+      const int total = __shfl(inc, 63, 64);
+      int pos = inc - cnt;
+      // the first hit: lowest set bit of the first non-empty lane
+      int mine = 0x7fffffff;
+#pragma unroll
+      for (int j = WPL - 1; j >= 0; --j)
+        if (w[j]) mine = 32 * (lane * WPL + j) + (__ffs(w[j]) - 1);
+      const int first = total ? wave_min_i32(mine) : 0;
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) {
+        unsigned x = w[j];
+        while (x && pos < ns) {
+          out[pos++] = 32 * (lane * WPL + j) + (__ffs(x) - 1);
+          x &= x - 1;
+        }
+      }
+      for (int l = min(total, ns) + lane; l < ns; l += 64) out[l] = first;
+    };
+    emit(mA, nsa, idxa + ((size_t)b * M + q) * nsa);
+    emit(mB, nsb, idxb + ((size_t)b * M + q) * nsb);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+extern "C" size_t sam6d_ball_query2_grid_workspace_bytes(int B, int N) {
+  return (size_t)B * ((bqg_cloud_bytes(N) + 15) & ~(size_t)15);
+}
+
+extern "C" int sam6d_ball_query2_grid(const float* new_xyz, const float* xyz, int B, int N, int M, float radius1, int nsample1, int* idx1,
+                                      float radius2, int nsample2, int* idx2, void* ws, size_t ws_bytes, void* stream) {
+  SAM6D_REQUIRE(new_xyz && xyz && idx1 && idx2 && ws, "ball_query2_grid: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && M >= 0 && nsample1 > 0 && nsample2 > 0 && B <= 65535, "ball_query2_grid: bad sizes");
+  SAM6D_REQUIRE((((size_t)ws) & 15) == 0 && ws_bytes >= sam6d_ball_query2_grid_workspace_bytes(B, N),
+                "ball_query2_grid: workspace too small / not 16-byte aligned (sam6d_ball_query2_grid_workspace_bytes)");
+  const float rmax = radius1 > radius2 ? radius1 : radius2;
+  if (N > BQG_MAXN || !(rmax > 0.f) || !(rmax < 1.0e30f))  // outside the pruned kernel's range: the all-pairs scan, same results
+    return sam6d_ball_query2(new_xyz, xyz, B, N, M, radius1, nsample1, idx1, radius2, nsample2, idx2, stream);
+  if (B == 0 || M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bqg_build_kernel, dim3(B), dim3(1024), 0, s, xyz, N, rmax * 1.001f, (unsigned char*)ws);
+  SAM6D_LAUNCH_CHECK_CONT("ball_query2_grid(build)");
+  const dim3 grid(cdiv(M, 4 * BQG_QPW), B);
+  const float r2a = radius1 * radius1, r2b = radius2 * radius2;  // fp32 products, as the reference (ball_query.cpp:20)
+  if (N <= 2048)
+    hipLaunchKernelGGL((bqg_query_kernel<1>), grid, dim3(256), 0, s, new_xyz, N, M, r2a, nsample1, idx1, r2b, nsample2, idx2, (const unsigned char*)ws);
+  else if (N <= 4096)
+    hipLaunchKernelGGL((bqg_query_kernel<2>), grid, dim3(256), 0, s, new_xyz, N, M, r2a, nsample1, idx1, r2b, nsample2, idx2, (const unsigned char*)ws);
+  else
+    hipLaunchKernelGGL((bqg_query_kernel<4>), grid, dim3(256), 0, s, new_xyz, N, M, r2a, nsample1, idx1, r2b, nsample2, idx2, (const unsigned char*)ws);
+  SAM6D_LAUNCH_CHECK("ball_query2_grid");
+}
+
 extern "C" int sam6d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius, int nsample,
                                 int* idx, void* stream) {
   SAM6D_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");

@@ -566,6 +566,118 @@ __device__ void rotation_from_H(const double H[9], double R[9]) {
     for (int j = 0; j < 3; ++j) R[i * 3 + j] = v1[i] * u1[j] + v2[i] * u2[j] + v3[i] * u3[j];
 }
 
+// The same rotation for a THREE-point hypothesis in closed form (no eigen-iteration).  The centred triples a_k (source) and b_k
+// (reference) each span a plane (H = sum w a_k b_k^T has rank <= 2; the 1e-5 in the weight normalisation of model_utils.py:381 leaves a
+// third singular value of ~1e-11 that the cross-product form above ignores as well).  With right-handed orthonormal frames E = (e1, e2,
+// e1 x e2) of the source plane and F of the reference plane, every candidate is R = F diag(Q, det Q) E^T with Q a 2 x 2 orthogonal
+// matrix, and tr(R H) = sum_pq Q_pq M_qp for the 2 x 2 in-plane correlation M_pq = sum_k w (a_k . e_p)(b_k . f_q):
+//   det M >= 0:  Q = rotation,   (c, s) ~ (M11 + M22, M12 - M21)      (tr = sigma1 + sigma2)
+//   det M <  0:  Q = reflection, (c, s) ~ (M11 - M22, M12 + M21), and the plane normal flips so that R stays proper
+// -- the maximiser the SVD formula V diag(1, 1, det(V U^T)) U^T returns.  ~150 fp64 operations and 6 square roots instead of up to 16
+// Jacobi sweeps with 6 fp64 divisions / square roots each (coarse_hyp_kernel: 205 -> see DESIGN).  Collinear or coincident triples
+// (a sampled pair repeated: rank <= 1, the reference's answer is LAPACK rounding noise) get a frame completed from the coordinate
+// axis least aligned with e1 -- finite, deterministic, a proper rotation.
+__device__ __forceinline__ void frame3(const double p[3][3], double e[3][3]) {
+  double n[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) n[k] = p[k][0] * p[k][0] + p[k][1] * p[k][1] + p[k][2] * p[k][2];
+  const int k0 = (n[0] >= n[1] && n[0] >= n[2]) ? 0 : (n[1] >= n[2] ? 1 : 2);
+  double e1[3] = {1.0, 0.0, 0.0};
+  double n1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k == k0) {
+      n1 = sqrt(n[k]);
+      if (n1 > 1e-150) { e1[0] = p[k][0] / n1; e1[1] = p[k][1] / n1; e1[2] = p[k][2] / n1; }
+    }
+  // the centred vector with the largest part orthogonal to e1
+  double q[3] = {0.0, 0.0, 0.0}, qn = -1.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double d = p[k][0] * e1[0] + p[k][1] * e1[1] + p[k][2] * e1[2];
+    const double x = p[k][0] - d * e1[0], y = p[k][1] - d * e1[1], z = p[k][2] - d * e1[2];
+    const double m = x * x + y * y + z * z;
+    if (m > qn) { qn = m; q[0] = x; q[1] = y; q[2] = z; }
+  }
+  double n2 = sqrt(qn > 0.0 ? qn : 0.0);
+  if (!(n2 > 1e-12 * n1) || !(n1 > 1e-150)) {  // collinear / coincident: complete the frame from the axis least aligned with e1
+    const int a = (fabs(e1[0]) <= fabs(e1[1]) && fabs(e1[0]) <= fabs(e1[2])) ? 0 : (fabs(e1[1]) <= fabs(e1[2]) ? 1 : 2);
+    const double d = e1[a];
+    q[0] = (a == 0 ? 1.0 : 0.0) - d * e1[0];
+    q[1] = (a == 1 ? 1.0 : 0.0) - d * e1[1];
+    q[2] = (a == 2 ? 1.0 : 0.0) - d * e1[2];
+    n2 = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  }
+  const double e2[3] = {q[0] / n2, q[1] / n2, q[2] / n2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { e[0][i] = e1[i]; e[1][i] = e2[i]; }
+  e[2][0] = e1[1] * e2[2] - e1[2] * e2[1];
+  e[2][1] = e1[2] * e2[0] - e1[0] * e2[2];
+  e[2][2] = e1[0] * e2[1] - e1[1] * e2[0];
+}
+
+// frame whose first axis is the direction of v (completed from the coordinate axis least aligned with it); v = 0 -> the identity frame
+__device__ __forceinline__ void frame_from_dir(const double v[3], double e[3][3]) {
+  const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  double e1[3] = {1.0, 0.0, 0.0};
+  if (n > 1e-150) { e1[0] = v[0] / n; e1[1] = v[1] / n; e1[2] = v[2] / n; }
+  const int a = (fabs(e1[0]) <= fabs(e1[1]) && fabs(e1[0]) <= fabs(e1[2])) ? 0 : (fabs(e1[1]) <= fabs(e1[2]) ? 1 : 2);
+  const double d = e1[a];
+  double q[3] = {(a == 0 ? 1.0 : 0.0) - d * e1[0], (a == 1 ? 1.0 : 0.0) - d * e1[1], (a == 2 ? 1.0 : 0.0) - d * e1[2]};
+  const double n2 = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { e[0][i] = e1[i]; e[1][i] = q[i] / n2; }
+  e[2][0] = e[0][1] * e[1][2] - e[0][2] * e[1][1];
+  e[2][1] = e[0][2] * e[1][0] - e[0][0] * e[1][2];
+  e[2][2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+}
+
+// a, b: the triples centred on their TRUE means ma, mb (see coarse_hyp_kernel)
+__device__ void rotation_3pt(const double a[3][3], const double b[3][3], const double ma[3], const double mb[3], double R[9]) {
+  double E[3][3], F[3][3];
+  double na = 0.0, nb = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    na = fmax(na, a[k][0] * a[k][0] + a[k][1] * a[k][1] + a[k][2] * a[k][2]);
+    nb = fmax(nb, b[k][0] * b[k][0] + b[k][1] * b[k][1] + b[k][2] * b[k][2]);
+  }
+  if (!(na > 1e-300) || !(nb > 1e-300)) {
+    // one of the triples is a single point sampled three times: H0 = 0, and what is left of the reference's H is the rank-1 trace of its
+    // shrunk centroids, 3 w d_a d_b^T with d_a ~ ma, d_b ~ mb -- its rotation turns the direction of ma into the direction of mb (twist
+    // undetermined).  The residual the caller computes depends on exactly that alignment, so it is reproduced.
+    frame_from_dir(ma, E);
+    frame_from_dir(mb, F);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[i * 3 + j] = F[0][i] * E[0][j] + F[1][i] * E[1][j] + F[2][i] * E[2][j];
+    return;
+  }
+  frame3(a, E);
+  frame3(b, F);
+  double M[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a1 = a[k][0] * E[0][0] + a[k][1] * E[0][1] + a[k][2] * E[0][2];
+    const double a2 = a[k][0] * E[1][0] + a[k][1] * E[1][1] + a[k][2] * E[1][2];
+    const double b1 = b[k][0] * F[0][0] + b[k][1] * F[0][1] + b[k][2] * F[0][2];
+    const double b2 = b[k][0] * F[1][0] + b[k][1] * F[1][1] + b[k][2] * F[1][2];
+    M[0][0] += a1 * b1; M[0][1] += a1 * b2; M[1][0] += a2 * b1; M[1][1] += a2 * b2;
+  }
+  const bool rot = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) >= 0.0;
+  double c = rot ? (M[0][0] + M[1][1]) : (M[0][0] - M[1][1]);
+  double s = rot ? (M[0][1] - M[1][0]) : (M[0][1] + M[1][0]);
+  const double r = sqrt(c * c + s * s);
+  if (r > 1e-300) { c /= r; s /= r; } else { c = 1.0; s = 0.0; }
+  // G = [[c, -s, 0], [s, c, 0], [0, 0, 1]] (rotation) or [[c, s, 0], [s, -c, 0], [0, 0, -1]] (reflection in the plane, normal flipped)
+  const double g00 = c, g01 = rot ? -s : s, g10 = s, g11 = rot ? c : -c, g22 = rot ? 1.0 : -1.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = F[0][i] * (g00 * E[0][j] + g01 * E[1][j]) + F[1][i] * (g10 * E[0][j] + g11 * E[1][j]) + F[2][i] * g22 * E[2][j];
+}
+
 // Coarse hypotheses (model_utils.py:244-257): sample s = 3h+k picks the pair (i1 = idx / N2, i2 = idx % N2);
 // R,t = procrustes(src = p2 triple -> ref = p1 triple), unit weights (thresh 0.5 keeps them), eps 1e-5;
 // dis = mean_k |(p1_k - t) R - p2_k|.
@@ -592,15 +704,22 @@ __global__ __launch_bounds__(256) void coarse_hyp_kernel(const int* __restrict__
     sc[d] = (p2[0][d] + p2[1][d] + p2[2][d]) * w;
     rc[d] = (p1[0][d] + p1[1][d] + p1[2][d]) * w;
   }
-  double H[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += (p2[k][i] - sc[i]) * (w * (p1[k][j] - rc[j]));
-      H[i * 3 + j] = s;
+  // H = sum_k (p2_k - sc) (w (p1_k - rc))^T (model_utils.py:384-389).  sc, rc are the reference's centroids -- sums times w = 1 / (3 + 1e-5),
+  // i.e. the true means shrunk by 3.3e-6 -- so its centred vectors carry a common offset d_a, d_b (up to 2.7e-5 for a cloud at z = 8).  In H
+  // the offsets cancel to first order (H = w H0 + 3 w d_a d_b^T with H0 from the TRUE means: the cross terms multiply sum_k (p_k - mean) = 0),
+  // so the rotation of H is the rotation of H0 to ~1e-10.  The closed form builds plane frames from the vectors themselves, where the
+  // offset would tilt the plane by d / |a| ~ 1e-4: it takes the vectors centred on the true means.
+  double ca[3][3], cb[3][3], ma[3], mb[3];
+  for (int d = 0; d < 3; ++d) {
+    ma[d] = (p2[0][d] + p2[1][d] + p2[2][d]) / 3.0;
+    mb[d] = (p1[0][d] + p1[1][d] + p1[2][d]) / 3.0;
+    for (int k = 0; k < 3; ++k) {
+      ca[k][d] = p2[k][d] - ma[d];
+      cb[k][d] = p1[k][d] - mb[d];
     }
+  }
   double R[9], t[3];
-  rotation_from_H(H, R);
+  rotation_3pt(ca, cb, ma, mb, R);
   for (int i = 0; i < 3; ++i) t[i] = rc[i] - (R[i * 3] * sc[0] + R[i * 3 + 1] * sc[1] + R[i * 3 + 2] * sc[2]);
   double acc = 0.0;
   for (int k = 0; k < 3; ++k) {
@@ -681,11 +800,121 @@ __global__ __launch_bounds__(256) void select_smallest_kernel(const float* __res
   if (i < n && rank < k) sel[(size_t)b * k + rank] = i;
 }
 
+// The same selection in O(n) instead of O(n^2): a three-level radix select (11 + 11 + 10 bits of the order-preserving integer image of
+// the floats) finds the k-th smallest value T and the number of smaller elements, the elements below T plus the first (k - that
+// number) elements EQUAL to T in index order are compacted, and only those k candidates are ranked against each other (the tie rule of
+// the rank counting above: equal values in index order).  Identical output, one workgroup per row: 6000 -> 300 in ~15 us instead of
+// 72 us of all-pairs comparisons.
+#define SR_T 1024
+__device__ __forceinline__ unsigned sr_key(float d) {
+  if (d == 0.0f) d = 0.0f;  // -0 and +0 compare equal in the rank rule
+  const unsigned u = __float_as_uint(d);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(SR_T) void select_radix_kernel(const float* __restrict__ dis, int n, int k, int* __restrict__ sel) {
+  extern __shared__ unsigned sr_keys[];        // n keys, then k candidate ids, then k candidate keys
+  __shared__ int hist[2048];
+  __shared__ int s_bin, s_before, s_cnt;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  unsigned* cand_id = sr_keys + n;
+  unsigned* cand_key = cand_id + k;
+  const float* d = dis + (size_t)b * n;
+  for (int i = t; i < n; i += SR_T) sr_keys[i] = sr_key(d[i]);
+  // level L: histogram of the bits [shift, shift + bits) of the keys whose higher bits equal `prefix`; the bin in which the cumulative
+  // count (plus `before`, the elements already known to be smaller) first exceeds k - 1 holds the k-th smallest
+  unsigned prefix = 0;
+  int before = 0;
+  const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+  for (int L = 0; L < 3; ++L) {
+    const int shift = shifts[L], bins = 1 << nbits[L];
+    for (int i = t; i < 2048; i += SR_T) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += SR_T) {
+      const unsigned u = sr_keys[i];
+      const bool in = (L == 0) || ((u >> (shift + nbits[L])) == prefix);
+      if (in) atomicAdd(&hist[(u >> shift) & (bins - 1)], 1);
+    }
+    __syncthreads();
+    if (t < 64) {  // one wave scans the bins: 32 per lane, then a wave prefix sum
+      const int per = bins / 64;
+      int sum = 0;
+      for (int j = 0; j < per; ++j) sum += hist[t * per + j];
+      int inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += nb;
+      }
+      const int excl = inc - sum;
+      const int need = k - 1 - before;  // 0-based rank of the wanted element among the elements of this level
+      if (need >= excl && need < inc) {  // exactly one lane
+        int run = excl;
+        for (int j = 0; j < per; ++j) {
+          const int c = hist[t * per + j];
+          if (need < run + c) { s_bin = t * per + j; s_before = before + run; break; }
+          run += c;
+        }
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << nbits[L]) | (unsigned)s_bin;
+    before = s_before;
+    __syncthreads();
+  }
+  const unsigned T = prefix;            // the k-th smallest key; `before` keys are smaller
+  const int need_eq = k - before;       // >= 1 elements equal to T are taken, lowest indices first
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  // keys below T: compacted in any order
+  for (int i = t; i < n; i += SR_T) {
+    const unsigned u = sr_keys[i];
+    if (u < T) {
+      const int slot = atomicAdd(&s_cnt, 1);
+      cand_id[slot] = (unsigned)i;
+      cand_key[slot] = u;
+    }
+  }
+  // keys equal to T: the first need_eq in index order (one wave walks the row, ballot + prefix popcount keeps the order)
+  if (t < 64) {
+    int taken = 0;
+    for (int i0 = 0; i0 < n && taken < need_eq; i0 += 64) {
+      const int i = i0 + lane;
+      const bool eq = i < n && sr_keys[i] == T;
+      const unsigned long long m = __ballot(eq);
+      const int pos = taken + __popcll(m & ((1ull << lane) - 1ull));
+      if (eq && pos < need_eq) {
+        cand_id[before + pos] = (unsigned)i;
+        cand_key[before + pos] = T;
+      }
+      taken += __popcll(m);
+    }
+  }
+  __syncthreads();
+  // rank the k candidates among themselves (value, then index)
+  for (int c = t; c < k; c += SR_T) {
+    const unsigned u = cand_key[c], id = cand_id[c];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+      const unsigned uj = cand_key[j];
+      rank += (uj < u || (uj == u && cand_id[j] < id)) ? 1 : 0;
+    }
+    sel[(size_t)b * k + rank] = (int)id;
+  }
+}
+
 extern "C" int sam6d_select_smallest(const float* dis, int B, int n, int k, int* sel, void* stream) {
   SAM6D_REQUIRE(dis && sel && B >= 0 && n > 0 && k > 0 && k <= n && n <= 15000 && B <= 65535, "select_smallest: bad arguments (n <= 15000)");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)((n + 3) & ~3) * 4, (hipStream_t)stream, dis, n, k,
-                     sel);
+  static int use_radix = -1;
+  if (use_radix < 0) {
+    const char* e = getenv("SAM6D_SELECT_RADIX");  // A/B switch: 0 = the all-pairs rank counting
+    use_radix = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (use_radix && (size_t)(n + 2 * k) * 4 <= 60000)  // (the default dynamic-LDS limit; longer rows keep the all-pairs kernel)
+    hipLaunchKernelGGL(select_radix_kernel, dim3(B), dim3(SR_T), (size_t)(n + 2 * k) * 4, (hipStream_t)stream, dis, n, k, sel);
+  else
+    hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)((n + 3) & ~3) * 4, (hipStream_t)stream, dis, n, k,
+                       sel);
   SAM6D_LAUNCH_CHECK("select_smallest");
 }
 
@@ -799,6 +1028,143 @@ __global__ __launch_bounds__(64) void pick_best_kernel(const float* __restrict__
   if (lane < 9) R[b * 9 + lane] = Rs[((size_t)b * nh + h) * 9 + lane];
   if (lane < 3) t[b * 3 + lane] = ts[((size_t)b * nh + h) * 3 + lane];
   if (lane == 0 && best_out) best_out[b] = h;
+}
+
+// ---- the same scoring on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), bit for bit the recipe above.
+// The K = 3 contraction x . y of pairwise_distance (model_utils.py:117: torch.matmul) is what the reference itself runs as a GEMM.  One
+// 32x32x2 instruction is the k-ordered chain fma(a1, b1, fma(a0, b0, c)) (scratch/ubench/mfma_f32_chain.hip: 0 mismatches), so with
+//     A (CAD point m)   = (-2 y0, -2 y1 | -2 y2, 1)        B (item = hypothesis, scene point) = (x0, x1 | x2, |x|^2)
+// two instructions on a zero accumulator give  fma(1, |x|^2, fma(-2 y2, x2, fma(-2 y1, x1, rn(-2 y0 x0))))  =  rn(|x|^2 - 2 xy)  with
+// xy = fma(x2, y2, fma(x1, y1, rn(x0 y0))) (scaling by -2 commutes with every rounding): exactly `fmaf(-2, xy, sx)` of the VALU kernel
+// for 1024 pairs per two instructions.  What is left for the vector ALU per pair: + |y|^2 and the running minimum (1.5 instructions
+// instead of 6).  A wave owns SM_CT column tiles of 32 items and walks the 32-row tiles of the CAD points, whose A operands and norms it
+// loads once per row tile for all its column tiles.  Items are (rank s of the hypothesis, scene point i) in one linear order per
+// proposal, so no lane idles at N1 = 196; the weighted distances go to a workspace and are summed per hypothesis in a fixed order by
+// score_sum_kernel; pick_best_kernel takes the arg-max (first maximum, model_utils.py:268).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define SM_CT 8
+#define SM_WAVES 4
+__global__ __launch_bounds__(SM_WAVES * 64) void score_hyp_mfma_kernel(const int* __restrict__ sel, const float* __restrict__ Rs,
+                                                                      const float* __restrict__ ts, const float* __restrict__ pts1,
+                                                                      const float* __restrict__ w1, const float* __restrict__ model,
+                                                                      const float* __restrict__ radius, int N1, int P, int Ppad, int nh,
+                                                                      int k, float* __restrict__ dw) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][Ppad]: -2 y0 | -2 y1 | -2 y2 | 1;  then [Ppad]: |y|^2 (+inf padding)
+  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 31, kk = lane >> 5;
+  const float den = radius[b] + 1e-6f;
+  const float* mb = model + (size_t)b * P * 3;
+  for (int i = t; i < Ppad; i += SM_WAVES * 64) {
+    float x = 0.f, y = 0.f, z = 0.f, sq = INFINITY;
+    if (i < P) {
+      x = mb[i * 3] / den; y = mb[i * 3 + 1] / den; z = mb[i * 3 + 2] / den;
+      sq = sqnorm3(x, y, z);
+    }
+    sm[i] = -2.0f * x; sm[Ppad + i] = -2.0f * y; sm[2 * Ppad + i] = -2.0f * z; sm[3 * Ppad + i] = 1.0f;
+    sm[4 * Ppad + i] = sq;
+  }
+  const long total = (long)k * N1;
+  const long e0 = ((long)(blockIdx.x * SM_WAVES + wave) * SM_CT) * 32 + j;
+  float b1[SM_CT], b2[SM_CT], mn[SM_CT];
+#pragma unroll
+  for (int c = 0; c < SM_CT; ++c) {
+    const long e = e0 + 32 * c;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, sx = 0.f;
+    if (e < total) {
+      const int s = (int)(e / N1), i = (int)(e - (long)s * N1);
+      const int h = sel[(size_t)b * k + s];
+      const float* R = Rs + ((size_t)b * nh + h) * 9;
+      const float* T = ts + ((size_t)b * nh + h) * 3;
+      const float* p = pts1 + ((size_t)b * N1 + i) * 3;
+      const float d0 = p[0] - T[0], d1 = p[1] - T[1], d2 = p[2] - T[2];
+      x0 = fmaf(d2, R[6], fmaf(d1, R[3], d0 * R[0]));
+      x1 = fmaf(d2, R[7], fmaf(d1, R[4], d0 * R[1]));
+      x2 = fmaf(d2, R[8], fmaf(d1, R[5], d0 * R[2]));
+      sx = sqnorm3(x0, x1, x2);
+    }
+    b1[c] = kk ? x1 : x0;
+    b2[c] = kk ? sx : x2;
+    mn[c] = INFINITY;
+  }
+  __syncthreads();
+  f32x16 zero;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) zero[v] = 0.f;
+  const float* a1p = sm + kk * Ppad + j;
+  const float* a2p = sm + (2 + kk) * Ppad + j;
+  const float* syp = sm + 4 * Ppad + kk * 4;
+  for (int r = 0; r < Ppad; r += 32) {
+    const float a1 = a1p[r], a2 = a2p[r];
+    const float4 s0 = *reinterpret_cast<const float4*>(syp + r), s1 = *reinterpret_cast<const float4*>(syp + r + 8);
+    const float4 s2 = *reinterpret_cast<const float4*>(syp + r + 16), s3 = *reinterpret_cast<const float4*>(syp + r + 24);
+    // software pipeline over the column tiles: the two instructions of tile c + 1 are issued before the vector work on tile c, into
+    // the other of two accumulator sets (one set: MFMA -> MFMA -> wait -> 26 vector instructions, strictly in series per wave)
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[0], zero, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[0], acc, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < SM_CT; ++c) {
+      f32x16 nxt = zero;
+      if (c + 1 < SM_CT) {
+        nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[c + 1], zero, 0, 0, 0);
+        nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[c + 1], nxt, 0, 0, 0);
+      }
+      // accumulator register v of this lane: CAD row r + 8 (v >> 2) + 4 kk + (v & 3), column j
+      const float m0 = fminf(fminf(acc[0] + s0.x, acc[1] + s0.y), fminf(acc[2] + s0.z, acc[3] + s0.w));
+      const float m1 = fminf(fminf(acc[4] + s1.x, acc[5] + s1.y), fminf(acc[6] + s1.z, acc[7] + s1.w));
+      const float m2 = fminf(fminf(acc[8] + s2.x, acc[9] + s2.y), fminf(acc[10] + s2.z, acc[11] + s2.w));
+      const float m3 = fminf(fminf(acc[12] + s3.x, acc[13] + s3.y), fminf(acc[14] + s3.z, acc[15] + s3.w));
+      mn[c] = fminf(fminf(mn[c], m0), fminf(fminf(m1, m2), m3));
+      acc = nxt;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < SM_CT; ++c) {
+    float m = fminf(mn[c], __shfl_xor(mn[c], 32, 64));
+    m = m < 0.0f ? 0.0f : m;
+    const long e = e0 + 32 * c;
+    if (kk == 0 && e < total) {
+      const int i = (int)(e % N1);
+      dw[(size_t)b * total + e] = sqrtf(m) * w1[(size_t)b * N1 + i];
+    }
+  }
+}
+
+// scores[s] = sum_i w1_i / (sum_i dw[s][i] + 1e-8) (model_utils.py:266-267), a wave per hypothesis: lane-strided partial sums, then the
+// wave butterfly -- a fixed order.  pick_best_kernel then takes the first maximum and its pose (model_utils.py:268-275).
+__global__ __launch_bounds__(256) void score_sum_kernel(const float* __restrict__ dw, const float* __restrict__ w1, int N1, int k,
+                                                        float* __restrict__ scores) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= k) return;
+  const float* d = dw + ((size_t)b * k + s) * N1;
+  float a = 0.f, c = 0.f;
+  for (int i = lane; i < N1; i += 64) {
+    a += w1[(size_t)b * N1 + i];
+    c += d[i];
+  }
+  a = wave_sum(a);
+  c = wave_sum(c);
+  if (lane == 0) scores[(size_t)b * k + s] = a / (c + 1e-8f);
+}
+
+extern "C" size_t sam6d_score_select_workspace_bytes(int B, int N1, int k) { return (size_t)B * N1 * k * 4; }
+
+extern "C" int sam6d_score_select_hypotheses_ws(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,
+                                                const float* model, const float* radius, int B, int N1, int P, int nh, int k,
+                                                float* scores, float* R, float* t, int* best, float* ws, size_t ws_bytes, void* stream) {
+  SAM6D_REQUIRE(sel && Rs && ts && pts1 && w1 && model && radius && scores && R && t && ws, "score_select_hypotheses_ws: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N1 > 0 && P > 0 && P <= 4096 && k > 0 && B <= 65535, "score_select_hypotheses_ws: bad sizes (P <= 4096)");
+  SAM6D_REQUIRE(ws_bytes >= (size_t)B * N1 * k * 4, "score_select_hypotheses_ws: workspace too small (sam6d_score_select_workspace_bytes)");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int Ppad = (P + 31) & ~31;
+  const long tiles = ((long)k * N1 + 31) / 32;
+  const int wgs = (int)((tiles + SM_WAVES * SM_CT - 1) / (SM_WAVES * SM_CT));
+  hipLaunchKernelGGL(score_hyp_mfma_kernel, dim3(wgs, B), dim3(SM_WAVES * 64), (size_t)Ppad * 20, s, sel, Rs, ts, pts1, w1, model, radius, N1,
+                     P, Ppad, nh, k, ws);
+  SAM6D_LAUNCH_CHECK_CONT("score_select_hypotheses_ws(score)");
+  hipLaunchKernelGGL(score_sum_kernel, dim3(cdiv(k, 4), B), dim3(256), 0, s, ws, w1, N1, k, scores);
+  SAM6D_LAUNCH_CHECK_CONT("score_select_hypotheses_ws(sum)");
+  hipLaunchKernelGGL(pick_best_kernel, dim3(B), dim3(64), 0, s, scores, sel, Rs, ts, nh, k, R, t, best);
+  SAM6D_LAUNCH_CHECK("score_select_hypotheses_ws");
 }
 
 extern "C" int sam6d_score_select_hypotheses(const int* sel, const float* Rs, const float* ts, const float* pts1, const float* w1,

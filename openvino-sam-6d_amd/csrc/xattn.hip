@@ -1,7 +1,11 @@
 // Cross attention of the sparse (197-token) transformer layers on the matrix cores, with the query projection inside
 // (TransformerLayer / AttentionLayer / MultiHeadAttention of PEM/model/transformer.py:95-150):
 //     q = x Wq^T + bq;   per head h:  P = softmax(q_h k_h^T / sqrt(64));   hidden[:, 64h .. 64h+64) = P v_h
-// k and v come from the key-side projection (one GEMM over the memory tokens, unchanged).
+// k and v come from the key-side projection: either one GEMM over the memory tokens beforehand (sam6d_cross_attention), or -- the
+// default path since round 3 -- computed HERE from the memory tokens (sam6d_cross_attention_kv, template flag KVP): the workgroup of
+// (cloud, head) holds Wk_h and Wv_h (64 rows x K = 256 each, 128 KiB of LDS; Wq_h and the k / v images take their place afterwards) and
+// projects the 197 memory tokens of its cloud with the same register-chained transposed products; k_h / v_h never reach HBM and the
+// separate (197 workgroups, launch-latency-bound) projection GEMM disappears: 12 launches per step.
 //
 // Before: proj_q GEMM (20 us) + a VALU attention kernel that walks the 197 keys of every query with wave butterflies (67 us), twelve
 // times per step.  Here one workgroup owns a (cloud, head): the 197 x 64 keys and values of that head are cut into fp16 hi / lo halves
@@ -23,6 +27,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define XA_WQ_BYTES 65536            // Wq_h image: 64 rows x 1 KiB (K = 256: hi | lo), also the v^T image (K = 224 keys + pad)
 #define XA_K_BYTES (XA_MAXKEY * 256) // k_h image: 208 rows x 256 B (K = 64: hi | lo)
 #define XA_LDS (XA_WQ_BYTES + XA_K_BYTES + 64)
+#define XA_LDS_KV (2 * XA_WQ_BYTES + 64)  // key / value projection inside: Wk_h | Wv_h resident together, the k image overlays Wv_h
 
 // slot p (0..31) of a 32-wide k-step <-> channel (see block.hip): channel = 16 (e >> 2) + 4 g + (e & 3), p = 8 g + e
 __device__ __forceinline__ int xa_channel_slot(int c) { return 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3); }
@@ -66,74 +71,188 @@ __device__ __forceinline__ void xa_mma(f32x4& acc, const unsigned char* __restri
 
 struct XaArgs {
   const float* x;     // (B, n, 256) query-side tokens
-  const float* kv;    // (B, m, 512): k | v of the memory tokens
+  const float* kv;    // KVP = false: (B, m, 512) k | v of the memory tokens;  KVP = true: (B, m, 256) the memory tokens themselves
   const unsigned char* wq;  // 4 heads x 64 KiB: proj_q rows 64h .. 64h+64 as two swizzled K = 256 panels (sam6d_pack_panels)
   const float* bq;    // (256)
   float* out;         // (B, n, 256)
   int n, m;
   float inv_wq;       // 1 / pack scale of Wq
   int half;           // 1: fp16 single product (matmul mode 2)
+  const unsigned char* wkv;  // KVP: 4 heads x (Wk_h 64 KiB | Wv_h 64 KiB), images like wq (sam6d_pack_panels of proj_k / proj_v rows)
+  const float* bkv;          // KVP: (512) proj_k.bias | proj_v.bias
+  float inv_wkv;             // KVP: 1 / pack scale of [Wk; Wv]
 };
 
+// the 16-token group `grp` of rows (b, tok, 256 channels) as split B fragments: returns the row scale
+__device__ __forceinline__ float xa_load_rows(const float* __restrict__ base, int tok, half8* xh, half8* xl, int fg) {
+  const float* src = base + (size_t)tok * 256;
+  float4 va[8], vb4[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
+    vb4[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+  }
+  float mx = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[s].x), fabsf(va[s].y)), fmaxf(fabsf(va[s].z), fabsf(va[s].w))));
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb4[s].x), fabsf(vb4[s].y)), fmaxf(fabsf(vb4[s].z), fabsf(vb4[s].w))));
+  }
+  const float sx = xa_pow2_scale(xa_tok_max(mx));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float e8[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb4[s].x, vb4[s].y, vb4[s].z, vb4[s].w};
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      unsigned hi, lo;
+      sam6d_split2_f16(e8[u] * sx, e8[u + 1] * sx, hi, lo);
+      const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+      const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+      xh[s][u] = h2[0];
+      xh[s][u + 1] = h2[1];
+      xl[s][u] = l2[0];
+      xl[s][u + 1] = l2[1];
+    }
+  }
+  return sx;
+}
+
+template <bool KVP>
 __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* regA = lds;                    // Wq_h image, later the v_h^T image
   unsigned char* kimg = lds + XA_WQ_BYTES;      // k_h image
-  float* red = reinterpret_cast<float*>(lds + XA_WQ_BYTES + XA_K_BYTES);  // 16 floats
+  float* red = reinterpret_cast<float*>(lds + (KVP ? 2 * XA_WQ_BYTES : XA_WQ_BYTES + XA_K_BYTES));  // 16 floats
   const int h = blockIdx.x, b = blockIdx.y;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   const int n = a.n, m = a.m;
   const bool half = a.half != 0;
 
-  // ---- Wq_h image by LDS-DMA (64 pieces of 1 KiB), k_h image built here from the fp32 keys
-  {
-    const unsigned char* src = a.wq + (size_t)h * XA_WQ_BYTES;
+  // 64 KiB image -> regA by LDS-DMA (64 pieces of 1 KiB)
+  auto dma64 = [&](const unsigned char* src, unsigned char* dst) {
 #pragma unroll
     for (int k = 0; k < 64 / XA_WAVES; ++k) {
       const int pc = wave + XA_WAVES * k;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
-                                       (void __attribute__((address_space(3)))*)(regA + pc * 1024), 16, 0, 0);
+                                       (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
     }
-  }
-  const float* kb = a.kv + (size_t)b * m * 512 + 64 * h;
-  const float* vb = kb + 256;
-  // this thread's share of the head's keys and values (element e = t + 512 i: key e >> 6, channel e & 63) goes to registers in one
-  // burst of independent loads -- a loop that loads, reduces and stores element by element pays one memory round trip per element
+  };
   constexpr int XA_EPT = (XA_MAXKEY * 64) / (XA_WAVES * 64);  // 26
-  float kreg[XA_EPT], vreg[XA_EPT];
-#pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
-    const bool ok = j < m;
-    kreg[i] = ok ? kb[(size_t)j * 512 + d] : 0.f;
-    vreg[i] = ok ? vb[(size_t)j * 512 + d] : 0.f;
-  }
-  float mk = 0.f, mv = 0.f;
-#pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    mk = fmaxf(mk, fabsf(kreg[i]));
-    mv = fmaxf(mv, fabsf(vreg[i]));
-  }
-  mk = wave_max_dpp(mk);
-  mv = wave_max_dpp(mv);
-  if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
-  __syncthreads();
+  float kreg[KVP ? 1 : XA_EPT], vreg[KVP ? 1 : XA_EPT];
+  f32x4 vacc[KVP ? 2 : 1][4];
   float sk = 0.f, sv = 0.f;
+  if constexpr (KVP) {
+    // ---- k_h = mem Wk_h^T + b, v_h = mem Wv_h^T + b for the m memory tokens of the cloud; a wave owns the token groups wave,
+    // wave + 8 (13 groups of 16), its k / v tiles stay in registers until the workgroup-wide maxima (the images' power-of-two
+    // scales) are known
+    const float* mb = a.kv + (size_t)b * m * 256;
+    const unsigned char* wk = a.wkv + (size_t)h * (2 * XA_WQ_BYTES);
+    const int mgroups = (m + 15) >> 4;
+    f32x4 kacc[2][4];
+    // Wk_h -> regA, Wv_h -> the k-image region + what follows it (regB, 64 KiB): both weight images are resident while the memory
+    // tokens are projected, so a token group's rows are loaded and split ONCE for its k and its v tiles
+    unsigned char* regB = kimg;
+    dma64(wk, regA);
+    dma64(wk + XA_WQ_BYTES, regB);
+    // the rows of this wave's first group are loaded and split while the weight DMA is in flight
+    float mk = 0.f, mv = 0.f;
+    half8 xh[8], xl[8];
+    float sx = 1.0f;
+    if (wave < mgroups) sx = xa_load_rows(mb, min(wave * 16 + fr, m - 1), xh, xl, fg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #pragma unroll
-  for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
-  sk = xa_pow2_scale(sk);
-  sv = xa_pow2_scale(sv);
-  // k_h image: every (key < 208, channel) slot is written (zeros beyond m), so no separate clearing pass
+    for (int gi = 0; gi < 2; ++gi) {
+      const int grp = wave + XA_WAVES * gi;
+      if (grp < mgroups) {  // (wave-uniform)
+        if (gi == 1) sx = xa_load_rows(mb, min(grp * 16 + fr, m - 1), xh, xl, fg);
+        const float inv = a.inv_wkv * (1.0f / sx);
 #pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
-    _Float16 hi, lo;
-    sam6d_split_f16(kreg[i] * sk, hi, lo);
-    const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);  // half index in the hi plane (K = 64)
-    _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
-    const int ch = p >> 3, cl = 8 + (p >> 3);
-    row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
-    row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
+        for (int i = 0; i < 4; ++i) {
+          f32x4 ak = f32x4{0.f, 0.f, 0.f, 0.f}, av = f32x4{0.f, 0.f, 0.f, 0.f};
+          xa_mma<1024, 32, 8>(ak, regA, 16 * i, xh, xl, fr, fg, half);
+          xa_mma<1024, 32, 8>(av, regB, 16 * i, xh, xl, fr, fg, half);
+          const float4 bk = *reinterpret_cast<const float4*>(a.bkv + 64 * h + 16 * i + 4 * fg);
+          const float4 bv = *reinterpret_cast<const float4*>(a.bkv + 256 + 64 * h + 16 * i + 4 * fg);
+          kacc[gi][i] = f32x4{ak[0] * inv + bk.x, ak[1] * inv + bk.y, ak[2] * inv + bk.z, ak[3] * inv + bk.w};
+          vacc[gi][i] = f32x4{av[0] * inv + bv.x, av[1] * inv + bv.y, av[2] * inv + bv.z, av[3] * inv + bv.w};
+          mk = fmaxf(mk, fmaxf(fmaxf(fabsf(kacc[gi][i][0]), fabsf(kacc[gi][i][1])), fmaxf(fabsf(kacc[gi][i][2]), fabsf(kacc[gi][i][3]))));
+          mv = fmaxf(mv, fmaxf(fmaxf(fabsf(vacc[gi][i][0]), fabsf(vacc[gi][i][1])), fmaxf(fabsf(vacc[gi][i][2]), fabsf(vacc[gi][i][3]))));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kacc[gi][i] = vacc[gi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    mk = wave_max_dpp(mk);
+    mv = wave_max_dpp(mv);
+    if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
+    __syncthreads();  // every wave is done with both weight images
+    dma64(a.wq + (size_t)h * XA_WQ_BYTES, regA);
+#pragma unroll
+    for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
+    sk = xa_pow2_scale(sk);
+    sv = xa_pow2_scale(sv);
+    // k_h image rows of this wave's tokens, over the Wv image (rows >= m are never read unmasked)
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int j = (wave + XA_WAVES * gi) * 16 + fr;
+      if (wave + XA_WAVES * gi < mgroups) {
+        _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * i + 4 * fg + r;
+            _Float16 hi, lo;
+            sam6d_split_f16(kacc[gi][i][r] * sk, hi, lo);
+            const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);
+            const int ch = p >> 3, cl = 8 + (p >> 3);
+            row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
+            row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
+          }
+      }
+    }
+  } else {
+    // ---- Wq_h image by LDS-DMA, k_h image built here from the fp32 keys
+    dma64(a.wq + (size_t)h * XA_WQ_BYTES, regA);
+    const float* kb = a.kv + (size_t)b * m * 512 + 64 * h;
+    const float* vb = kb + 256;
+    // this thread's share of the head's keys and values (element e = t + 512 i: key e >> 6, channel e & 63) goes to registers in one
+    // burst of independent loads -- a loop that loads, reduces and stores element by element pays one memory round trip per element
+#pragma unroll
+    for (int i = 0; i < XA_EPT; ++i) {
+      const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+      const bool ok = j < m;
+      kreg[i] = ok ? kb[(size_t)j * 512 + d] : 0.f;
+      vreg[i] = ok ? vb[(size_t)j * 512 + d] : 0.f;
+    }
+    float mk = 0.f, mv = 0.f;
+#pragma unroll
+    for (int i = 0; i < XA_EPT; ++i) {
+      mk = fmaxf(mk, fabsf(kreg[i]));
+      mv = fmaxf(mv, fabsf(vreg[i]));
+    }
+    mk = wave_max_dpp(mk);
+    mv = wave_max_dpp(mv);
+    if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
+    sk = xa_pow2_scale(sk);
+    sv = xa_pow2_scale(sv);
+    // k_h image: every (key < 208, channel) slot is written (zeros beyond m), so no separate clearing pass
+#pragma unroll
+    for (int i = 0; i < XA_EPT; ++i) {
+      const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+      _Float16 hi, lo;
+      sam6d_split_f16(kreg[i] * sk, hi, lo);
+      const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);  // half index in the hi plane (K = 64)
+      _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
+      const int ch = p >> 3, cl = 8 + (p >> 3);
+      row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
+      row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
+    }
   }
 
   // ---- phase 1: q^T for this wave's token groups (kept as split B fragments: 2 k-steps each)
@@ -211,16 +330,38 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   // Cleared first: the key slots 208 .. 255 are multiplied by zero probabilities only, but must not hold NaN patterns.
   for (int i = t; i < XA_WQ_BYTES / 16; i += XA_WAVES * 64) reinterpret_cast<uint4*>(regA)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
+  if constexpr (KVP) {
 #pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
-    _Float16 hi, lo;
-    sam6d_split_f16(vreg[i] * sv, hi, lo);
-    const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
-    _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
-    const int ch = p >> 3, cl = 32 + (p >> 3);
-    row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
-    row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+    for (int gi = 0; gi < 2; ++gi) {
+      const int j = (wave + XA_WAVES * gi) * 16 + fr;
+      if (j < m) {  // key slots >= m stay zero
+        const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
+        const int ch = p >> 3, cl = 32 + (p >> 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * i + 4 * fg + r;
+            _Float16 hi, lo;
+            sam6d_split_f16(vacc[gi][i][r] * sv, hi, lo);
+            _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
+            row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
+            row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < XA_EPT; ++i) {
+      const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+      _Float16 hi, lo;
+      sam6d_split_f16(vreg[i] * sv, hi, lo);
+      const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
+      _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
+      const int ch = p >> 3, cl = 32 + (p >> 3);
+      row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
+      row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+    }
   }
   __syncthreads();
 
@@ -286,6 +427,20 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   }
 }
 
+static int xa_reserve() {
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)xattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS_KV);
+    if (e != hipSuccess) {
+      sam6d_set_error("cross_attention: cannot reserve %d bytes of LDS: %s", XA_LDS, hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&done);
+  }
+  return 0;
+}
+
 extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void* wq_image, const float* bq, float inv_wq_scale,
                                      float* out, int B, int n, int m, void* stream) {
   SAM6D_REQUIRE(x && kv && wq_image && bq && out && B >= 0, "cross_attention: null pointer");
@@ -295,16 +450,27 @@ extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void
                 "cross_attention: pointers must be 16-byte aligned");
   SAM6D_REQUIRE(B <= 65535 && inv_wq_scale > 0.f, "cross_attention: bad arguments");
   if (B == 0) return 0;
-  static unsigned long long done = 0;
-  if (sam6d_first_use_on_device(&done)) {
-    hipError_t e = hipFuncSetAttribute((const void*)xattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
-    if (e != hipSuccess) {
-      sam6d_set_error("cross_attention: cannot reserve %d bytes of LDS: %s", XA_LDS, hipGetErrorString(e));
-      return (int)e;
-    }
-    sam6d_setup_done_on_device(&done);
-  }
-  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2)};
-  hipLaunchKernelGGL(xattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
+  if (int rc = xa_reserve()) return rc;
+  XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2), nullptr, nullptr, 1.0f};
+  hipLaunchKernelGGL(xattn_kernel<false>, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention");
+}
+
+extern "C" long sam6d_cross_attention_kv_image_bytes(void) { return 4L * 2 * XA_WQ_BYTES; }
+
+extern "C" int sam6d_cross_attention_kv(const float* x, const float* mem, const void* wq_image, const float* bq, float inv_wq_scale,
+                                        const void* wkv_image, const float* bkv, float inv_wkv_scale, float* out, int B, int n, int m,
+                                        void* stream) {
+  SAM6D_REQUIRE(x && mem && wq_image && bq && wkv_image && bkv && out && B >= 0, "cross_attention_kv: null pointer");
+  SAM6D_REQUIRE(n > 0 && n <= 16 * 2 * XA_WAVES && m > 0 && m <= XA_MAXKEY,
+                "cross_attention_kv: needs n <= %d queries and m <= %d keys per cloud", 16 * 2 * XA_WAVES, XA_MAXKEY);
+  SAM6D_REQUIRE(((((size_t)x) | ((size_t)mem) | ((size_t)wq_image) | ((size_t)bq) | ((size_t)wkv_image) | ((size_t)bkv) | ((size_t)out)) & 15) == 0,
+                "cross_attention_kv: pointers must be 16-byte aligned");
+  SAM6D_REQUIRE(B <= 65535 && inv_wq_scale > 0.f && inv_wkv_scale > 0.f, "cross_attention_kv: bad arguments");
+  if (B == 0) return 0;
+  if (int rc = xa_reserve()) return rc;
+  XaArgs a{x, mem, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2), (const unsigned char*)wkv_image, bkv,
+           inv_wkv_scale};
+  hipLaunchKernelGGL(xattn_kernel<true>, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS_KV, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("cross_attention_kv");
 }

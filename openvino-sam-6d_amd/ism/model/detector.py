@@ -15,6 +15,21 @@ except Exception:  # not installed here: a plain Module has everything the scori
     _Base = nn.Module
 
 
+class RefAux:
+    """Stand-in for the gathered template descriptors compute_appearance_score returns in the reference (detector.py:303): holds the
+    reduced similarity of the fused launch; `.tensor()` builds the reference's (N,P,D) tensor on demand."""
+
+    def __init__(self, ps):
+        self.ps = ps
+
+    def tensor(self):
+        return self.ps.gathered_reference()
+
+    @property
+    def shape(self):
+        return (self.ps.Ns, self.ps.P, self.ps.ref.shape[-1])
+
+
 class Instance_Segmentation_Model(_Base):
     def __init__(self, segmentor_model, descriptor_model, onboarding_config, matching_config, post_processing_config,
                  log_interval, log_dir, visible_thred, pointcloud_sample_num, **kwargs):
@@ -42,8 +57,18 @@ class Instance_Segmentation_Model(_Base):
 
     # -- detector.py:298-308 ----------------------------------------------------------------------------------
     def compute_appearance_score(self, best_pose, pred_objects_idx, qurey_appe_descriptors):
-        ref = self.ref_data["appe_descriptors"][pred_objects_idx, best_pose, ...].contiguous()  # (N, P, D) gather
+        """-> (appe_scores, ref_aux_descriptor).  The reference gathers ref_data["appe_descriptors"][pred_objects_idx, best_pose] into a
+        new (N,P,D) tensor, multiplies, and hands the gathered tensor back for compute_geometric_score to multiply AGAIN.  Here one
+        launch reads the chosen templates in place and keeps the row / column maxima both scores need; the second return value is a
+        RefAux handle (a stand-in for the gathered tensor: pass it on to compute_geometric_score as the reference's caller does,
+        ISM/run_inference_custom.py:236-250; `.tensor()` materialises the reference's tensor for any other use)."""
         q = qurey_appe_descriptors.contiguous()
+        ref_all = self.ref_data["appe_descriptors"]
+        P, D = q.shape[1], q.shape[2]
+        if ref_all.dim() == 4 and P % 128 == 0 and D % 32 == 0 and ref_all.dtype == torch.float32 and q.dtype == torch.float32:
+            ps = _ism.patch_scores_fused(q, ref_all, pred_objects_idx, best_pose)
+            return ps.scores()[0], RefAux(ps)
+        ref = ref_all[pred_objects_idx, best_pose, ...].contiguous()  # (N, P, D) gather: shapes the fused kernel is not built for
         self._sim_cache = (_ism.patch_similarity(q, ref), q.data_ptr(), ref.data_ptr())
         return _ism.patch_scores(self._sim_cache[0], q)[0], ref
 
@@ -68,13 +93,16 @@ class Instance_Segmentation_Model(_Base):
     # -- detector.py:310-322 ----------------------------------------------------------------------------------
     def compute_geometric_score(self, image_uv, proposals, appe_descriptors, ref_aux_descriptor, visible_thred=0.5):
         q = appe_descriptors.contiguous()
-        ref = ref_aux_descriptor.contiguous()
-        cache = getattr(self, "_sim_cache", None)
-        if cache is not None and cache[1] == q.data_ptr() and cache[2] == ref.data_ptr():
-            sim = cache[0]  # the reference recomputes the same matmul: reuse it
+        if isinstance(ref_aux_descriptor, RefAux) and ref_aux_descriptor.ps.q_ptr == q.data_ptr():
+            visible_ratio = ref_aux_descriptor.ps.scores(visible_thred)[1]  # the maxima of compute_appearance_score's launch
         else:
-            sim = _ism.patch_similarity(q, ref)
-        visible_ratio = _ism.patch_scores(sim, q, visible_thred)[1]
+            ref = (ref_aux_descriptor.tensor() if isinstance(ref_aux_descriptor, RefAux) else ref_aux_descriptor).contiguous()
+            cache = getattr(self, "_sim_cache", None)
+            if cache is not None and cache[1] == q.data_ptr() and cache[2] == ref.data_ptr():
+                sim = cache[0]  # the reference recomputes the same matmul: reuse it
+            else:
+                sim = _ism.patch_similarity(q, ref)
+            visible_ratio = _ism.patch_scores(sim, q, visible_thred)[1]
         bc = getattr(self, "_xyxy_cache", None)
         if bc is not None and bc[0] == image_uv.data_ptr():
             xyxy = bc[1]

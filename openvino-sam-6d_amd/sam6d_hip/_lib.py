@@ -22,6 +22,8 @@ SIGNATURES = {
     "sam6d_gather_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_ball_query": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
     "sam6d_ball_query2": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_f, c_i, c_p, c_p],
+    "sam6d_ball_query2_grid_workspace_bytes": [c_i, c_i],
+    "sam6d_ball_query2_grid": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_f, c_i, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
@@ -40,6 +42,8 @@ SIGNATURES = {
     "sam6d_transpose": [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_p],
     "sam6d_geo_embed_cheb": [c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
     "sam6d_attention": [c_p] * 6 + [c_i] * 3 + [c_l] * 8 + [c_p],
+    "sam6d_scaled_softmax": [c_p, c_p, c_f, c_l, c_i, c_l, c_l, c_p, c_l, c_p],
+    "sam6d_sinusoid_embed": [c_p, c_l, c_p, c_i, c_p, c_p],
     "sam6d_linattn_focus_k": [c_p, c_p, c_l, c_l, c_p],
     "sam6d_linattn_kv": [c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p, c_p, c_p],
     "sam6d_linattn_focus_q": [c_p, c_p, c_p, c_i, c_l, c_l, c_p],
@@ -58,11 +62,16 @@ SIGNATURES = {
     "sam6d_coarse_hypotheses": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_select_smallest": [c_p, c_i, c_i, c_i, c_p, c_p],
     "sam6d_score_select_hypotheses": [c_p] * 7 + [c_i] * 5 + [c_p] * 5,
+    "sam6d_score_select_workspace_bytes": [c_i, c_i, c_i],
+    "sam6d_score_select_hypotheses_ws": [c_p] * 7 + [c_i] * 5 + [c_p] * 5 + [ctypes.c_size_t, c_p],
     "sam6d_fine_assign": [c_p, c_i, c_i, c_i] + [c_p] * 10,
     "sam6d_weighted_procrustes": [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p],
     "sam6d_ism_cosine": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_ism_semantic": [c_p, c_i, c_i, c_i, c_i, c_f] + [c_p] * 6,
     "sam6d_ism_patch_scores": [c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    "sam6d_ism_patch_fused_workspace_bytes": [c_i, c_i],
+    "sam6d_ism_patch_fused": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, ctypes.c_size_t, c_p],
+    "sam6d_ism_patch_fused_scores": [c_p, c_i, c_i, c_f, c_p, c_p, c_p],
     "sam6d_ism_project": [c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
@@ -87,12 +96,14 @@ SIGNATURES = {
     "sam6d_fine_match_workspace_bytes_n": [c_i, c_i],
     "sam6d_fine_match": [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_cross_attention": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],
+    "sam6d_cross_attention_kv": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],
     "sam6d_pack_panels": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p],
     "sam6d_rpe_front_image_bytes": [],
     "sam6d_rpe_front": [c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_l, c_p],
     "sam6d_rpe_front_vt": [c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_p, c_l, c_p, c_i, c_i, c_p],
     "sam6d_token_block_image_bytes": [c_i],
     "sam6d_linattn_kv_image_bytes": [],
+    "sam6d_cross_attention_kv_image_bytes": [],
     "sam6d_linattn_kv_pack": [c_p, c_i, c_p, c_p, c_p],
     "sam6d_linattn_kv_image": [c_p, c_p, c_i, c_i, c_l, c_l, c_p, c_p, c_p, c_p],
     "sam6d_token_block": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],

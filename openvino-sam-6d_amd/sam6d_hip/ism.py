@@ -58,6 +58,51 @@ def patch_scores(sim, q_appe, thred=0.5):
     return appe, vis
 
 
+class PatchScores:
+    """Row / column maxima of the patch similarity of every selected proposal against its best template (the workspace of
+    sam6d_ism_patch_fused): what compute_appearance_score and compute_geometric_score both need, without the (Ns,P,P) tensor."""
+    __slots__ = ("ws", "Ns", "P", "q_ptr", "obj", "best", "ref")
+
+    def scores(self, thred=0.5):
+        """-> appearance score (Ns,), visible ratio (Ns,)   (ISM/model/loss.py:52-62, 64-76)"""
+        dev = self.ws.device
+        appe = torch.empty(self.Ns, dtype=torch.float32, device=dev)
+        vis = torch.empty(self.Ns, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sam6d_ism_patch_fused_scores", self.ws.data_ptr(), self.Ns, self.P, float(thred), _p(appe), _p(vis), _s())
+        return appe, vis
+
+    def gathered_reference(self):
+        """the (Ns,P,D) tensor the reference's compute_appearance_score returns (detector.py:303) -- built only when asked for"""
+        return self.ref[self.obj, self.best, ...].contiguous()
+
+
+@on_tensor_device
+def patch_scores_fused(q_appe, ref_appe, pred_obj, best_pose, q_index=None):
+    """q_appe (Nq,P,D) query patch descriptors (rows q_index when given, else Nq == Ns), ref_appe (No,Nt,P,D) ALL templates' patch
+    descriptors, pred_obj / best_pose (Ns,) i64 -> PatchScores.  One GEMM launch whose tiles end in row / column maxima."""
+    from .ops import _chk
+    q_appe = q_appe.contiguous()
+    ref_appe = ref_appe.contiguous()
+    _chk(q_appe, "q_appe", torch.float32, 3)
+    _chk(ref_appe, "ref_appe", torch.float32, 4)
+    No, Nt, P, D = ref_appe.shape
+    obj = pred_obj.to(torch.int64).contiguous()
+    best = best_pose.to(torch.int64).contiguous()
+    qi = q_index.to(torch.int64).contiguous() if q_index is not None else None
+    Ns = obj.shape[0]
+    if q_appe.shape[1:] != (P, D) or best.shape[0] != Ns or (qi is None and q_appe.shape[0] != Ns) or (qi is not None and qi.shape[0] != Ns):
+        raise RuntimeError("patch_scores_fused: shapes do not match (q %s, ref %s, %d proposals)" % (tuple(q_appe.shape), tuple(ref_appe.shape), Ns))
+    if P % 128 or D % 32:
+        raise NotImplementedError("patch_scores_fused: P must be a multiple of 128 and D of 32 (got %d, %d)" % (P, D))
+    nbytes = int(_lib.load().sam6d_ism_patch_fused_workspace_bytes(Ns, P))
+    ps = PatchScores()
+    ps.ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q_appe.device)
+    ps.Ns, ps.P, ps.q_ptr, ps.obj, ps.best, ps.ref = Ns, P, q_appe.data_ptr(), obj, best, ref_appe
+    _lib.call("sam6d_ism_patch_fused", _p(q_appe), _p(qi), _p(ref_appe), _p(obj), _p(best), Ns, Nt, P, D, ps.ws.data_ptr(), nbytes, _s())
+    return ps
+
+
 @on_tensor_device
 def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale):
     """ISM/model/detector.py:209-246: -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3)."""

@@ -26,7 +26,7 @@ def _s():
 class _Flags:
     """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
     ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front")
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid")
 
     def __init__(self):
         env = os.environ.get
@@ -35,6 +35,9 @@ class _Flags:
         self.fused_block = self.mode >= 1 and env("SAM6D_FUSED_BLOCK", "1") == "1"
         self.fused_ln = self.mode >= 1 and env("SAM6D_FUSED_LN", "0") == "1"
         self.fused_front = self.fused_block and env("SAM6D_FUSED_FRONT", "1") == "1"
+        self.score_mfma = env("SAM6D_SCORE_MFMA", "1") == "1"  # hypothesis scoring: distance products on the fp32 matrix cores
+        self.bq_grid = env("SAM6D_BQ_GRID", "1") == "1"  # ball queries through the cell grid (identical indices)
+        self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
 
 
 _FLAGS = None
@@ -174,6 +177,20 @@ def pack_cross_query(q):
     return dict(img=img, inv=1.0 / s_q)
 
 
+def pack_cross_kv(kv):
+    """[proj_k; proj_v] of a cross-attention layer (kv.w (512,256): rows 0..255 proj_k, 256..511 proj_v) as the per-head panel images of
+    csrc/xattn.hip's in-kernel key / value projection: head h -> Wk rows 64h..64h+64 (2 panels) | Wv rows 64h..64h+64 (2 panels)."""
+    s_kv = _pow2_scale(kv.w.abs().max())
+    nbytes = int(_lib.load().sam6d_cross_attention_kv_image_bytes())
+    assert nbytes == 16 * TB_P256
+    img = torch.zeros(nbytes, dtype=torch.uint8, device=kv.w.device)
+    for h in range(H):
+        for part in range(2):  # 0: proj_k, 1: proj_v
+            _lib.call("sam6d_pack_panels", _p(kv.w, (part * C + 64 * h) * C), C, 64, 0, 8, float(s_kv),
+                      img.data_ptr() + (4 * h + 2 * part) * TB_P256, _s())
+    return dict(img=img, inv=1.0 / s_kv)
+
+
 class PemWeights:
     """Device-resident weights in the layouts the kernels want, built from a reference-keyed state_dict
     (SURVEY 8b B2).  Packing is pure data movement: concatenating q/k/v projection weights, transposing proj_p, folding
@@ -248,6 +265,7 @@ class PemWeights:
                       torch.cat([g(ca + ".proj_k.bias"), g(ca + ".proj_v.bias")], 0)),
             **self._post(g, c))
         cross_l["xq"] = pack_cross_query(cross_l["q"])
+        cross_l["xkv"] = pack_cross_kv(cross_l["kv"])
         return dict(self=self_l, cross=cross_l)
 
 
@@ -341,13 +359,17 @@ def layernorm(x2d, gb, out=None):
     return out
 
 
-def _post_attention(hidden, x2d, L):
+def _post_attention(hidden, x2d, L, out=None):
     """linear -> +residual -> LayerNorm -> AttentionOutput (expand, ReLU, squeeze, +residual, LayerNorm)
-    (PEM/model/transformer.py:152-199)."""
+    (PEM/model/transformer.py:152-199).  out: optional contiguous destination holding M x 256 floats."""
+    M = hidden.shape[0]
+    if out is not None:
+        assert out.is_contiguous() and out.numel() == M * C
+        out = out.view(M, C)
     if _fused_block() and "tb" in L:
         # linear + residual + LayerNorm + FFN + residual + LayerNorm in ONE launch: the 128-token tile never leaves the chip
-        M = hidden.shape[0]
-        out = _empty((M, C), hidden)
+        if out is None:
+            out = _empty((M, C), hidden)
         tb = L["tb"]
         with _Timed("token_block"):
             _lib.call("sam6d_token_block", _p(hidden), _p(x2d), tb["img"].data_ptr(), _p(tb["cst"]), _p(out), M, 1e-5, _s())
@@ -357,10 +379,14 @@ def _post_attention(hidden, x2d, L):
     if _flags().fused_ln:
         y = gemm_ln(hidden, L["lin"], x2d, L["n1"])
         h = linear(y, L["exp"], act=1)
-        return gemm_ln(h, L["sq"], y, L["n2"])
+        r = gemm_ln(h, L["sq"], y, L["n2"])
+        if out is not None:
+            _lib.call("sam6d_copy_f32", _p(r), _p(out), r.numel(), _s())
+            return out
+        return r
     y = layernorm(linear(hidden, L["lin"], residual=x2d), L["n1"])
     h = linear(y, L["exp"], act=1)
-    return layernorm(linear(h, L["sq"], residual=y), L["n2"])
+    return layernorm(linear(h, L["sq"], residual=y), L["n2"], out=out)
 
 
 def _fused_block():
@@ -647,23 +673,97 @@ def rpe_self_layer(x, E, L):
     return _post_attention(hid, x2, L).reshape(Bp, n, C)
 
 
-def cross_layer(x, mem, L):
-    """x (B,n,256) attends to mem (B,m,256)   TransformerLayer (PEM/model/transformer.py:95-226)."""
+def cross_layer(x, mem, L, out=None):
+    """x (B,n,256) attends to mem (B,m,256)   TransformerLayer (PEM/model/transformer.py:95-226).  out: optional (B,n,256) view to write
+    the layer's output into (a slice of the caller's stacked token buffer)."""
     B, n, _ = x.shape
     m = mem.shape[1]
     x2 = x.reshape(B * n, C)
-    kv = linear(mem.reshape(B * m, C), L["kv"])  # (B*m, 512): k | v
     hid = _empty((B * n, C), x)
     if _fused_block() and "xq" in L and n <= 256 and m <= 208:
-        # proj_q + softmax attention of all four heads in one launch on the matrix cores (xattn.hip)
+        # proj_q, proj_k, proj_v + softmax attention of all four heads in one launch on the matrix cores (xattn.hip)
         with _Timed("cross_attention"):
-            _lib.call("sam6d_cross_attention", _p(x2), _p(kv), L["xq"]["img"].data_ptr(), _p(L["q"].b), float(L["xq"]["inv"]), _p(hid),
-                      B, n, m, _s())
-        return _post_attention(hid, x2, L).reshape(B, n, C)
+            if "xkv" in L and _flags().xattn_kv:
+                _lib.call("sam6d_cross_attention_kv", _p(x2), _p(mem), L["xq"]["img"].data_ptr(), _p(L["q"].b), float(L["xq"]["inv"]),
+                          L["xkv"]["img"].data_ptr(), _p(L["kv"].b), float(L["xkv"]["inv"]), _p(hid), B, n, m, _s())
+            else:
+                kv = linear(mem.reshape(B * m, C), L["kv"])  # (B*m, 512): k | v
+                _lib.call("sam6d_cross_attention", _p(x2), _p(kv), L["xq"]["img"].data_ptr(), _p(L["q"].b), float(L["xq"]["inv"]), _p(hid),
+                          B, n, m, _s())
+        return _post_attention(hid, x2, L, out=out).reshape(B, n, C)
+    kv = linear(mem.reshape(B * m, C), L["kv"])  # (B*m, 512): k | v
     q = linear(x2, L["q"])
     _lib.call("sam6d_attention", _p(q), _p(kv), _p(kv, C), None, None, _p(hid), B, n, m, C, 2 * C, 2 * C, C, n * C, m * 2 * C,
               m * 2 * C, n * C, _s())
-    return _post_attention(hid, x2, L).reshape(B, n, C)
+    return _post_attention(hid, x2, L, out=out).reshape(B, n, C)
+
+
+# ------------------------------------------------------------------------------ stand-alone sub-module forwards (drop-in API)
+@on_tensor_device
+def sinusoid_embedding(x, div_term, d_model):
+    """x (n) -> (n, d_model)   SinusoidalPositionalEmbedding.forward (PEM/model/transformer.py:269-285)."""
+    n = x.numel()
+    out = _empty((n, d_model), x)
+    dt = div_term.detach().float().contiguous()
+    _lib.call("sam6d_sinusoid_embed", _p(x), n, _p(dt), int(d_model), _p(out), _s())
+    return out
+
+
+@on_tensor_device
+def mha_forward(xq, xk, xv, lq, lk, lv, heads=H, embed_qk=None, proj_p=None):
+    """MultiHeadAttention.forward / RPEMultiHeadAttention.forward (PEM/model/transformer.py:111-150, 383-420) as separate launches,
+    WITH the attention probabilities as an output: xq (B,N,C), xk / xv (B,M,C) [, embed_qk (B,N,M,C)] -> hidden (B,N,C),
+    probabilities (B,heads,N,M).  The fused kernels (sam6d_cross_attention_kv, sam6d_rpe_scores) are what the pipeline uses."""
+    B, N, Cm = xq.shape
+    M = xk.shape[1]
+    if Cm != C or heads != H:
+        raise ValueError("kernels are specialised for d_model=256, num_heads=4 (PEM/config/base.yaml)")
+    q = linear(xq.reshape(B * N, C), lq)
+    k = linear(xk.reshape(B * M, C), lk)
+    v = linear(xv.reshape(B * M, C), lv)
+    ldp = (M + 3) // 4 * 4
+    qk = torch.zeros((B * N, H, ldp), dtype=torch.float32, device=xq.device)  # rows = query tokens, [head][key]
+    gemm_b2(q, k, qk, N, M, 64, C, C, H * ldp, B, N * C, M * C, N * H * ldp, H, 64, 64, ldp)
+    sp = None
+    if embed_qk is not None:
+        # q . proj_p(E) = (Wp_h^T q_h) . E + q_h . b_p;  the bias term is constant over the keys and cancels in the softmax
+        wpT = proj_p.w.t().contiguous()
+        qp = _empty((B * N, H * C), xq)
+        gemm(q, wpT, None, qp, B * N, C, 64, C, C, H * C, batch=H, sA=64, sW=64, sC=C, act=16)
+        sp = torch.zeros((B * N, H, ldp), dtype=torch.float32, device=xq.device)
+        gemm(qp, embed_qk, None, sp, H, M, C, C, C, ldp, batch=B * N, sA=H * C, sW=M * C, sC=H * ldp, act=16)
+    P = torch.zeros((B * N, H, ldp), dtype=torch.float32, device=xq.device)
+    _lib.call("sam6d_scaled_softmax", _p(qk), _p(sp), 0.125, B * N * H, M, ldp, ldp, _p(P), ldp, _s())
+    vT = torch.zeros((B, C, ldp), dtype=torch.float32, device=xq.device)
+    _lib.call("sam6d_transpose", _p(v), C, M * C, B, M, C, _p(vT), ldp, C * ldp, _s())
+    hid = _empty((B * N, C), xq)
+    gemm_b2(P, vT, hid, N, 64, M, H * ldp, ldp, C, B, N * H * ldp, C * ldp, N * C, H, ldp, 64 * ldp, 64)
+    probs = P.reshape(B, N, H, ldp)[..., :M].permute(0, 2, 1, 3).contiguous()
+    return hid.reshape(B, N, C), probs
+
+
+@on_tensor_device
+def linear_attention_forward(xq, xk, xv, lq, lk, lv, scale, heads=H):
+    """LinearAttention.forward (PEM/model/transformer.py:548-578): xq (B,I,C), xk / xv (B,J,C) -> (B,I,C); the kv contraction order."""
+    B, I, Cm = xq.shape
+    J = xk.shape[1]
+    if Cm != C or heads != H:
+        raise ValueError("kernels are specialised for d_model=256, num_heads=4 (PEM/config/base.yaml)")
+    if not (I * J * 128 > 64 * 64 * (I + J)):
+        raise NotImplementedError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
+    q = linear(xq.reshape(B * I, C), lq)
+    kv = _empty((B * J, 2 * C), xq)
+    gemm(xk.reshape(B * J, C), lk.w, lk.b, kv, B * J, C, C, C, C, 2 * C)
+    gemm(xv.reshape(B * J, C), lv.w, lv.b, kv, B * J, C, C, C, C, 2 * C, c_off=C)
+    _lib.call("sam6d_linattn_focus_k", _p(kv), _p(scale), B * J, 2 * C, _s())
+    kvT = _empty((B, H, 64, 64), xq)
+    ksum = _empty((B, H, 64), xq)
+    _lib.call("sam6d_linattn_kv", _p(kv), _p(kv, C), B, J, 2 * C, 2 * C, J * 2 * C, J * 2 * C, _p(kvT), _p(ksum), _s())
+    _lib.call("sam6d_linattn_focus_q", _p(q), _p(scale), _p(ksum), B, I, C, _s())
+    hid = _empty((B * I, C), xq)
+    for h in range(H):
+        gemm(q, kvT, None, hid, I, 64, 64, C, 64, C, a_off=h * 64, w_off=h * 4096, c_off=h * 64, batch=B, sA=I * C, sW=H * 4096, sC=I * C)
+    return hid.reshape(B, I, C)
 
 
 def geometric_transformer(S, E, T):
@@ -671,9 +771,10 @@ def geometric_transformer(S, E, T):
     (GeometricTransformer blocks ['self','cross'], sequential cross: PEM/model/transformer.py:483-527)."""
     B = S.shape[0] // 2
     S = rpe_self_layer(S, E, T["self"])
-    f0 = cross_layer(S[:B], S[B:], T["cross"])
-    f1 = cross_layer(S[B:], f0, T["cross"])
-    return _stack(f0, f1)
+    out = torch.empty_like(S)  # the two cross layers write their halves of the stacked result directly (no copy pass)
+    f0 = cross_layer(S[:B], S[B:], T["cross"], out=out[:B])
+    cross_layer(S[B:], f0, T["cross"], out=out[B:])
+    return out
 
 
 def _stack(a, b):
@@ -742,7 +843,15 @@ def pe_group(pts, r1=0.1, r2=0.2, ns1=32, ns2=64):
     q = _empty((Bp, N, 3), pts)
     _lib.call("sam6d_add_scalar", _p(pts), 0.00000001, Bp * N * 3, _p(q), _s())
     idx12 = (_empty((Bp, N, ns1), pts, torch.int32), _empty((Bp, N, ns2), pts, torch.int32))
-    _lib.call("sam6d_ball_query2", _p(q), _p(pts), Bp, N, N, float(r1), ns1, _p(idx12[0]), float(r2), ns2, _p(idx12[1]), _s())
+    if _flags().bq_grid:
+        nbytes = int(_lib.load().sam6d_ball_query2_grid_workspace_bytes(Bp, N))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+        with _Timed("ball_query"):
+            _lib.call("sam6d_ball_query2_grid", _p(q), _p(pts), Bp, N, N, float(r1), ns1, _p(idx12[0]), float(r2), ns2, _p(idx12[1]),
+                      ws.data_ptr(), nbytes, _s())
+        return idx12
+    with _Timed("ball_query"):
+        _lib.call("sam6d_ball_query2", _p(q), _p(pts), Bp, N, N, float(r1), ns1, _p(idx12[0]), float(r2), ns2, _p(idx12[1]), _s())
     return idx12
 
 
@@ -822,8 +931,16 @@ def compute_coarse_Rt(att, pts1, pts2, model, radius, rand, n_proposal1=6000, n_
     Rb = _empty((B, 3, 3), att)
     tb = _empty((B, 3), att)
     best = _empty((B,), att, torch.int32)
-    _lib.call("sam6d_score_select_hypotheses", _p(sel), _p(Rs), _p(ts), _p(pts1), _p(w1), _p(model), _p(radius), B, N1,
-              model.shape[1], n_proposal1, n_proposal2, _p(scores), _p(Rb), _p(tb), _p(best), _s())
+    if model.shape[1] <= 4096 and _flags().score_mfma:
+        # the K = 3 distance contraction on the fp32 matrix cores (same bits), weighted distances staged in a workspace
+        ws = _empty((B * N1 * n_proposal2,), att)
+        with _Timed("score_hyp"):
+            _lib.call("sam6d_score_select_hypotheses_ws", _p(sel), _p(Rs), _p(ts), _p(pts1), _p(w1), _p(model), _p(radius), B, N1,
+                      model.shape[1], n_proposal1, n_proposal2, _p(scores), _p(Rb), _p(tb), _p(best), _p(ws), ws.numel() * 4, _s())
+    else:
+        with _Timed("score_hyp"):
+            _lib.call("sam6d_score_select_hypotheses", _p(sel), _p(Rs), _p(ts), _p(pts1), _p(w1), _p(model), _p(radius), B, N1,
+                      model.shape[1], n_proposal1, n_proposal2, _p(scores), _p(Rb), _p(tb), _p(best), _s())
     if return_aux:
         return Rb, tb, dict(weights=w, w1=w1, idx=idx, dis=dis, top=sel, scores=scores, best=best, Rs=Rs, ts=ts, cum=cum)
     return Rb, tb

@@ -316,6 +316,45 @@ def fx_transformer(ext, mods):
     save("transformer", seed=14, rpe=rpe, cross=crs, f0=f0, f1=f1)
 
 
+def fx_submodules(ext, mods):
+    """Every sub-module forward of the reference's transformer.py that a caller can reach directly (SinusoidalPositionalEmbedding,
+    MultiHeadAttention, AttentionLayer, AttentionOutput, RPEMultiHeadAttention, RPEAttentionLayer, LinearAttention, LinearAttentionLayer):
+    outputs on the seeded layer inputs of fx_transformer / fx_linear_attention, sub-sampled rows."""
+    T = mods["transformer"]
+    sd = synth.make_pem_weights(1)
+    p = "coarse_point_matching.transformers.0"
+    m = T.GeometricTransformer(blocks=["self", "cross"], d_model=256, num_heads=4, dropout=None,
+                               activation_fn="ReLU", return_attention_scores=False).eval()
+    m.load_state_dict(sub_sd(sd, p), strict=True)
+    x, y, e0, e1 = _layer_inputs(14)
+    emb = T.SinusoidalPositionalEmbedding(256)
+    idx = torch.tensor([[0.0, 0.37, 1.0, 4.5], [11.25, 23.9, 57.0, 866.0254]])
+    with torch.no_grad():
+        sin = emb(idx)
+        rpe_l, cross_l = m.layers[0], m.layers[1]
+        r_hid, r_sc = rpe_l.attention.attention(x, x, x, e0)
+        r_out, r_sc2 = rpe_l.attention(x, x, e0)
+        ffn = rpe_l.output(x)
+        c_hid, c_sc = cross_l.attention.attention(x, y, y)
+        c_out, _ = cross_l.attention(x, y)
+    assert torch.equal(r_sc, r_sc2)
+    pf = "fine_point_matching.transformers.0"
+    s2d = T.SparseToDenseTransformer(256, num_heads=4, sparse_blocks=["self", "cross"], dropout=None, activation_fn="ReLU",
+                                     focusing_factor=3, with_bg_token=True, replace_bg_token=True).eval()
+    s2d.load_state_dict(sub_sd(sd, pf), strict=True)
+    g = gen(15)
+    d0 = torch.randn(1, 2049, 256, generator=g)
+    d1 = torch.randn(1, 2049, 256, generator=g)
+    q_in, m_in = d0[:, 1:].contiguous(), d1[:, 1:197].contiguous()
+    with torch.no_grad():
+        la = s2d.dense_layer.attention.attention(q_in, m_in, m_in)
+        lal = s2d.dense_layer.attention(q_in, m_in)
+    # (div_term is a registered buffer -- it travels with the checkpoint; torch.exp on another CPU can differ in the last bit)
+    save("submodules", seed=14, seed_dense=15, sin_idx=idx, sin=sin, sin_div_term=emb.div_term, rpe_hidden=r_hid[:, ::4], rpe_scores=r_sc[:, :, ::8],
+         rpe_attn_out=r_out[:, ::4], ffn_out=ffn[:, ::4], mha_hidden=c_hid[:, ::4], mha_scores=c_sc[:, :, ::8], attn_out=c_out[:, ::4],
+         linattn=la[:, ::16], linattn_layer=lal[:, ::16])
+
+
 def fx_linear_attention(ext, mods):
     T = mods["transformer"]
     sd = synth.make_pem_weights(1)
@@ -795,7 +834,7 @@ def fx_rle():
     save("rle", seed=21, masks=masks.to(torch.uint8), counts=np.asarray(flat, np.int32), offsets=np.asarray(offs, np.int64))
 
 
-ALL = ["pointops", "pairwise", "geo", "transformer", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
+ALL = ["pointops", "pairwise", "geo", "transformer", "submodules", "linear_attention", "pos_encoding", "similarity", "coarse_rt",
        "fine_rt", "procrustes", "pem_e2e", "depth_cloud", "test_data", "config1", "ism", "rle"]
 
 if __name__ == "__main__":

@@ -254,6 +254,69 @@ def test_cross_attention_vs_fp64(dev, B, n, m, xs):
     assert err < 2e-6 * max(1.0, float(want.abs().max())), "cross attention vs fp64: %.3e" % err
 
 
+@pytest.mark.parametrize("B,n,m,xs", [(2, 197, 197, 1.0), (3, 50, 208, 1.0), (1, 16, 1, 1.0), (2, 64, 32, 1.0), (2, 197, 197, 3.0e4),
+                                      (2, 130, 197, 1.0e-5), (1, 197, 100, 1.0)])
+def test_cross_attention_kv_vs_fp64(dev, B, n, m, xs):
+    """sam6d_cross_attention_kv -- proj_q, proj_k, proj_v and the 4-head softmax attention of MultiHeadAttention in ONE launch
+    (PEM/model/transformer.py:111-150), the memory tokens as input -- against a float64 recompute; xs scales the query-side tokens and
+    1 / xs the key projection (see test_cross_attention_vs_fp64).  Also: equal to proj GEMM + sam6d_cross_attention within rounding."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(B * 100 + n + m + 7)
+    mk = lambda o, i: ((torch.rand(o, i, generator=gen) * 2 - 1) / math.sqrt(i), (torch.rand(o, generator=gen) * 2 - 1) / math.sqrt(i))
+    qw, qb = mk(256, 256)
+    kw, kb = mk(256, 256)
+    vw, vb = mk(256, 256)
+    x = torch.randn(B, n, 256, generator=gen) * xs
+    mem = torch.randn(B, m, 256, generator=gen)
+    qb = qb * xs
+    kw, kb = kw / xs, kb / xs
+    d = lambda t: t.double()
+    qq = d(x) @ d(qw).t() + d(qb)
+    kk = d(mem) @ d(kw).t() + d(kb)
+    vv = d(mem) @ d(vw).t() + d(vb)
+    want = torch.zeros(B, n, 256, dtype=torch.float64)
+    for h in range(4):
+        sl = slice(64 * h, 64 * h + 64)
+        att = torch.softmax(qq[..., sl] @ kk[..., sl].transpose(1, 2) / 8.0, dim=-1)
+        want[..., sl] = att @ vv[..., sl]
+    qd = pem.Linear(qw.to(dev), qb.to(dev))
+    kvd = pem.Linear(torch.cat([kw, vw], 0).to(dev), torch.cat([kb, vb], 0).to(dev))
+    xq, xkv = pem.pack_cross_query(qd), pem.pack_cross_kv(kvd)
+    xd, md = x.to(dev).contiguous(), mem.to(dev).contiguous()
+    out = torch.full((B, n, 256), float("nan"), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("sam6d_cross_attention_kv", xd.data_ptr(), md.data_ptr(), xq["img"].data_ptr(), qd.b.data_ptr(), float(xq["inv"]),
+              xkv["img"].data_ptr(), kvd.b.data_ptr(), float(xkv["inv"]), out.data_ptr(), B, n, m, st)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < 2e-6 * max(1.0, float(want.abs().max())), "cross attention (kv inside) vs fp64: %.3e" % err
+    kvt = pem.linear(md.reshape(B * m, 256), kvd)
+    out2 = torch.full((B, n, 256), float("nan"), device=dev)
+    _lib.call("sam6d_cross_attention", xd.data_ptr(), kvt.data_ptr(), xq["img"].data_ptr(), qd.b.data_ptr(), float(xq["inv"]),
+              out2.data_ptr(), B, n, m, st)
+    assert float((out2.cpu().double() - got).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_geometric_transformer_writes_stacked_halves(dev):
+    """The two sequential cross layers write their halves of the stacked (2B, n, 256) result in place: equal to the layers called one
+    by one (PEM/model/transformer.py:517-524: feats1 attends to the already-updated feats0)."""
+    from sam6d_hip import pem, synth
+    W = pem.PemWeights(synth.make_pem_weights(1), dev)
+    T = W.coarse["blocks"][1]
+    gen = torch.Generator().manual_seed(8)
+    B, n = 3, 197
+    S = torch.randn(2 * B, n, 256, generator=gen).to(dev)
+    pts = (torch.rand(2 * B, n - 1, 3, generator=gen) - 0.5).to(dev)
+    pb = torch.cat([torch.full((2 * B, 1, 3), 100.0, device=dev), pts], 1).contiguous()
+    E = pem.geo_embedding(pb, W)
+    got = pem.geometric_transformer(S, E, T)
+    s1 = pem.rpe_self_layer(S, E, T["self"])
+    f0 = pem.cross_layer(s1[:B].contiguous(), s1[B:].contiguous(), T["cross"])
+    f1 = pem.cross_layer(s1[B:].contiguous(), f0, T["cross"])
+    assert torch.equal(got[:B], f0) and torch.equal(got[B:], f1)
+
+
 def test_cross_layer_fused_matches_unfused(dev, monkeypatch):
     from sam6d_hip import pem, synth
     W = pem.PemWeights(synth.make_pem_weights(1), dev)

@@ -90,6 +90,38 @@ def test_ism_pipeline_golden(dev, ism_model):
     _close(fin_q, want_q, 1e-6, "final score with the 0.0 IoU quirk")
 
 
+def test_fused_patch_scores_equal_materialised_path(dev, ism_model):
+    """compute_appearance_score / compute_geometric_score through the fused launch (templates read in place, row / column maxima kept,
+    no (N,256,256) similarity tensor) against the materialised path (gather + GEMM + reduction) and the oracle; the RefAux handle the
+    drop-in returns in place of the gathered tensor materialises to exactly the reference's gather; q_index reads the query patches
+    in place as well."""
+    from oracle import ism_oracle as IO
+    from sam6d_hip import ism
+    m, loss = ism_model
+    g = golden("ism")
+    d = ism_inputs(int(g["seed"]))
+    r_appe = d["r_appe"].to(dev)
+    m.ref_data = {"descriptors": d["ref"].to(dev), "appe_descriptors": r_appe, "poses": d["poses"].to(dev), "pointcloud": d["pc"].to(dev)}
+    sel, obj, sem, best = m.compute_semantic_score(d["q"].to(dev))
+    q_all = d["q_appe"].to(dev)
+    qa = q_all[sel].contiguous()
+    appe, aux = m.compute_appearance_score(best, obj, qa)
+    assert type(aux).__name__ == "RefAux", "the fused path must be what the drop-in runs at these shapes"
+    ref_sel = r_appe[obj, best].contiguous()
+    assert torch.equal(aux.tensor(), ref_sel)
+    sim = ism.patch_similarity(qa, ref_sel)
+    a2, v2 = ism.patch_scores(sim, qa, 0.5)
+    ps = ism.patch_scores_fused(q_all, r_appe, obj, best, q_index=sel)
+    a3, v3 = ps.scores(0.5)
+    assert torch.equal(a3, appe), "q_index path differs from the gathered-query path"
+    _close(appe, a2.cpu(), 2e-6, "appearance: fused vs materialised")
+    _close(v3, v2.cpu(), 1e-6, "visible ratio: fused vs materialised")
+    _close(appe, g["appe"], 5e-6, "appearance vs the reference")
+    _close(v3, g["vis"], 2e-6, "visible ratio vs the reference")
+    for thr in (0.3, 0.7):
+        _close(ps.scores(thr)[1], ism.patch_scores(sim, qa, thr)[1].cpu(), 1e-6, "visible ratio at threshold %g" % thr)
+
+
 def test_translation_matches_fp64_reference_path(dev, ism_model):
     """K / depth_scale arrive as float64 from the reference's caller (run_inference_custom.py:87-94): the whole
     translation is then float64 in the reference; the kernel must agree to fp32 rounding."""

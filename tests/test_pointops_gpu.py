@@ -205,6 +205,51 @@ def test_ball_query2_equals_two_single_queries(dev, B, N, M, r1, ns1, r2, ns2):
     assert torch.equal(i1, single[0]) and torch.equal(i2, single[1])
 
 
+@pytest.mark.parametrize("B,N,M,r1,ns1,r2,ns2,kind", [
+    (2, 2048, 2048, 0.1, 32, 0.2, 64, "cube"), (32, 2048, 2048, 0.1, 32, 0.2, 64, "cube"), (1, 5000, 300, 0.05, 16, 0.4, 64, "cube"),
+    (3, 100, 100, 0.3, 8, 0.01, 4, "cube"), (3, 3000, 1500, 0.3, 8, 0.02, 5, "cube"), (2, 2048, 2048, 0.1, 32, 0.2, 64, "dense"),
+    (2, 2048, 2048, 0.1, 32, 0.2, 64, "outliers"), (2, 7000, 900, 0.2, 32, 0.1, 64, "surface"), (1, 5, 9, 0.5, 4, 1.0, 8, "cube"),
+    (2, 2048, 2048, 0.1, 32, 0.2, 64, "lattice"), (1, 9000, 64, 0.1, 32, 0.2, 64, "cube")])
+def test_ball_query2_grid_equals_all_pairs_scan(dev, B, N, M, r1, ns1, r2, ns2, kind):
+    """sam6d_ball_query2_grid (cell grid + per-query hit bit mask) returns, bit for bit, what the all-pairs scan returns -- which the
+    tests above pin to EXT/src/ball_query.cpp:16-62 through the oracle / the compiled reference: uniform cubes, a cloud denser than the
+    ball (every point a hit: the first-nsample-in-index-order rule decides), far outliers (clamped cells), a thin surface, queries far
+    outside the cloud, points exactly on cell boundaries (lattice), N beyond the pruned kernel's range (falls back)."""
+    from oracle import pointops as P
+    from sam6d_hip import _lib
+    g = torch.Generator().manual_seed(N * 3 + M + len(kind))
+    xyz = torch.rand(B, N, 3, generator=g) - 0.5
+    if kind == "dense":
+        xyz = xyz * 0.08
+    elif kind == "outliers":
+        xyz[:, ::97] *= 400.0
+        xyz[:, 5] = -1.0e4
+    elif kind == "surface":
+        xyz[..., 2] = 0.02 * torch.sin(6 * xyz[..., 0])
+    elif kind == "lattice":
+        xyz = torch.round(xyz * 10) * 0.1001 * 2  # coordinates on multiples of the cell edge 0.2002
+    new = (xyz[:, :M] + 1e-8).contiguous() if M <= N else (torch.rand(B, M, 3, generator=g) - 0.5)
+    new[:, 0] = 5.0  # an empty ball, outside the cloud's box
+    if M > 2:
+        new[:, 1] = -7.0
+    xyz, new = xyz.to(dev).contiguous(), new.to(dev).contiguous()
+    a1 = torch.full((B, M, ns1), -7, dtype=torch.int32, device=dev)
+    a2 = torch.full((B, M, ns2), -7, dtype=torch.int32, device=dev)
+    _lib.call("sam6d_ball_query2", new.data_ptr(), xyz.data_ptr(), B, N, M, float(r1), ns1, a1.data_ptr(), float(r2), ns2, a2.data_ptr(), None)
+    g1 = torch.full((B, M, ns1), -9, dtype=torch.int32, device=dev)
+    g2 = torch.full((B, M, ns2), -9, dtype=torch.int32, device=dev)
+    nbytes = int(_lib.load().sam6d_ball_query2_grid_workspace_bytes(B, N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call("sam6d_ball_query2_grid", new.data_ptr(), xyz.data_ptr(), B, N, M, float(r1), ns1, g1.data_ptr(), float(r2), ns2, g2.data_ptr(),
+              ws.data_ptr(), nbytes, None)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, a1), "radius %g: %d of %d query rows differ" % (r1, int((g1 != a1).any(dim=2).sum()), B * M)
+    assert torch.equal(g2, a2), "radius %g: %d of %d query rows differ" % (r2, int((g2 != a2).any(dim=2).sum()), B * M)
+    if B * N * M <= 3 * 3000 * 1500:  # and against the oracle itself where that takes seconds
+        assert torch.equal(g1.cpu(), P.ball_query(new.cpu(), xyz.cpu(), r1, ns1))
+        assert torch.equal(g2.cpu(), P.ball_query(new.cpu(), xyz.cpu(), r2, ns2))
+
+
 def test_fps_grid_barrier_abort_falls_back(dev):
     """The multi-workgroup FPS (N > 4096) closes every round with a hand-rolled grid-wide barrier that needs all its workgroups on the
     chip.  When a workgroup gives up waiting (forced here: spin cap 0) the cloud is recomputed by the one-workgroup kernel queued behind
