@@ -262,6 +262,12 @@ int sam6d_linattn_focus_q(float* q, const float* scale, const float* ksum, int B
 int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
                      const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
                      const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream);
+/* sam6d_pe_mlp_max (PositionalEncoding's SharedMLPs, PEM/model/fine_point_matching.py:113-144) with an upper bound on the persistent
+ * workgroups of the split-precision kernel (0 = fill the chip, 3 per CU): a launch that runs beside another stream's kernels leaves
+ * them LDS and registers with 256 or 512. */
+int sam6d_pe_mlp_max_wg(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1, const float* sh1,
+                        const float* W2, const float* sc2, const float* sh2, const float* W3, const float* sc3, const float* sh3,
+                        float* out, long ldo, int off, int max_wg, void* stream);
 
 /* y = (x - t) @ R per batch element (PEM/model/fine_point_matching.py:45). */
 int sam6d_rigid_inverse(const float* x, const float* R, const float* t, int B, int N, float* y, void* stream);

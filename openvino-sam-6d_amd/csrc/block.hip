@@ -287,13 +287,17 @@ __device__ __forceinline__ void tb_load_step(const unsigned (&a)[4], tb_u32x4* f
 }
 // Fragment ring of TB_FD + 1 steps: the reads of step S + TB_FD are issued before the six MFMAs of step S (one step of MFMAs, 96
 // cycles, does not cover the LDS latency when all eight waves of the CU stream b128 reads).
+// Deeper rings were measured on the 197-token layers (round 3): two steps ahead within the same register budget 48.1 us against 48.3 us,
+// three steps with a 4-slot panel ring and one wave per SIMD 52.5 us -- s_memtime stamps (scratch/tb_stamps.py) put a K = 256 panel at
+// ~1420 cycles against 768 of MFMA issue with the waits for DMA and barrier at ~100 + ~160: the four waves of a workgroup each re-read
+// the whole panel from LDS (64 LDS cycles per 96-cycle k-step), which a longer look-ahead does not change.
 #define TB_FD 1
-template <int KS, int S>
+template <int KS, int S, int FD_>
 __device__ __forceinline__ void tb_mma_step(f32x4& acc0, f32x4& acc1, const unsigned (&a)[4], const half8* __restrict__ xh,
-                                            const half8* __restrict__ xl, tb_u32x4 (&f)[TB_FD + 1][4], bool half) {
-  constexpr int cur = S % (TB_FD + 1);
-  if constexpr (S + TB_FD < KS) tb_load_step<KS, S + TB_FD>(a, f[(S + TB_FD) % (TB_FD + 1)]);
-  constexpr int newer = (KS - 1 - S) < TB_FD ? (KS - 1 - S) : TB_FD;  // steps requested after this one
+                                            const half8* __restrict__ xl, tb_u32x4 (&f)[FD_ + 1][4], bool half) {
+  constexpr int cur = S % (FD_ + 1);
+  if constexpr (S + FD_ < KS) tb_load_step<KS, S + FD_>(a, f[(S + FD_) % (FD_ + 1)]);
+  constexpr int newer = (KS - 1 - S) < FD_ ? (KS - 1 - S) : FD_;  // steps requested after this one
   tb_wait<4 * newer>(f[cur][0], f[cur][1], f[cur][2], f[cur][3]);
   const half8 h0 = __builtin_bit_cast(half8, f[cur][0]), l0 = __builtin_bit_cast(half8, f[cur][1]);
   const half8 h1 = __builtin_bit_cast(half8, f[cur][2]), l1 = __builtin_bit_cast(half8, f[cur][3]);
@@ -305,20 +309,20 @@ __device__ __forceinline__ void tb_mma_step(f32x4& acc0, f32x4& acc1, const unsi
   }
   acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xh[S], acc0, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xh[S], acc1, 0, 0, 0);
-  if constexpr (S + 1 < KS) tb_mma_step<KS, S + 1>(acc0, acc1, a, xh, xl, f, half);
+  if constexpr (S + 1 < KS) tb_mma_step<KS, S + 1, FD_>(acc0, acc1, a, xh, xl, f, half);
 }
 // `panel`: LDS byte address of the panel; rows fr (first out tile) and fr + 16 (second)
-template <int KS>
+template <int KS, int FD = TB_FD>
 __device__ __forceinline__ void tb_mma(f32x4& acc0, f32x4& acc1, unsigned panel, const half8* __restrict__ xh,
                                        const half8* __restrict__ xl, int fr, int fg, bool half) {
   const unsigned rowbase = panel + fr * TB_ROWB(KS);
   const unsigned a[4] = {rowbase + (((0 + fg) ^ fr) << 4), rowbase + (((4 + fg) ^ fr) << 4), rowbase + (((8 + fg) ^ fr) << 4),
                          rowbase + (((12 + fg) ^ fr) << 4)};
-  tb_u32x4 f[TB_FD + 1][4];
+  tb_u32x4 f[FD + 1][4];
   tb_load_step<KS, 0>(a, f[0]);
-  if constexpr (TB_FD >= 2 && KS >= 2) tb_load_step<KS, 1>(a, f[1]);
-  if constexpr (TB_FD >= 3 && KS >= 3) tb_load_step<KS, 2>(a, f[2]);
-  tb_mma_step<KS, 0>(acc0, acc1, a, xh, xl, f, half);
+  if constexpr (FD >= 2 && KS >= 2) tb_load_step<KS, 1>(a, f[1]);
+  if constexpr (FD >= 3 && KS >= 3) tb_load_step<KS, 2>(a, f[2]);
+  tb_mma_step<KS, 0, FD>(acc0, acc1, a, xh, xl, f, half);
 }
 
 // a token's channels live in the four lanes 16 apart (g = lane >> 4): reductions over the token
@@ -443,7 +447,19 @@ struct TbSched {
   }
 };
 
-template <int MODE, int WAVES, int NBUF>
+#ifdef TB_STAMP  // diagnostic build only (scratch/stamp): per-wave s_memtime stamps around every panel's wait / barrier
+#define TB_NSTAMP 256
+__device__ unsigned long long tb_stamps[512 * 8 * TB_NSTAMP];
+extern "C" int sam6d_tb_debug_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tb_stamps), sizeof(unsigned long long) * 512 * 8 * TB_NSTAMP);
+}
+// (stamps go to LDS and are flushed at the end: a global store before a panel's s_waitcnt vmcnt would itself be waited for)
+#define TB_ST(i) do { if (lane == 0 && (i) < TB_NSTAMP) st_lds[wave][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TB_ST(i)
+#endif
+
+template <int MODE, int WAVES, int NBUF, int FD = TB_FD>
 __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) {  // (2 waves per SIMD: <= 256 VGPR + AGPR)
   constexpr int TB_TOK = 16 * WAVES, TB_NBUF = NBUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -453,6 +469,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   typedef TbSched<MODE, WAVES> SCH;
   const bool half = a.half != 0;
+#ifdef TB_STAMP
+  __shared__ unsigned long long st_lds[WAVES][TB_NSTAMP];
+  unsigned long long* st_base = tb_stamps + ((size_t)(blockIdx.x < 512 ? blockIdx.x : 0) * 8 + wave) * TB_NSTAMP;
+#endif
+  TB_ST(0);
   const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)pan;
 
   // ---- which rows
@@ -502,8 +523,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     constexpr int I = decltype(IC)::value;
     static_assert(NBUF == 2 || (32 % WAVES) == 0, "counted waits need the same number of pieces in every wave");
     constexpr int N = SCH::template in_flight<NBUF>(I);
+    TB_ST(4 + 3 * I);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    TB_ST(5 + 3 * I);
     __syncthreads();
+    TB_ST(6 + 3 * I);
     dma(std::integral_constant<int, I + NBUF - 1>{});
     return pan_lds + (I % TB_NBUF) * TB_PANEL_BYTES;
   };
@@ -561,6 +585,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     }
   }
 
+  TB_ST(1);
   f32x4 acc[16];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -573,7 +598,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     tb_static_for<0, 8>([&](auto J) {
       constexpr int j = decltype(J)::value;
       const unsigned p = next_panel(std::integral_constant<int, j>{});
-      tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
+      tb_mma<8, FD>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
     });
     {
       const float inv = cst[TC_SC + 0] * (1.0f / sx);
@@ -617,7 +642,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     tb_static_for<0, 8>([&](auto J) {
       constexpr int j = decltype(J)::value;
       const unsigned p = next_panel(std::integral_constant<int, 8 + j>{});
-      tb_mma<2>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg, half);
+      tb_mma<2, FD>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg, half);
     });
     {
       const float inv = a.kvinv[b] * (1.0f / sx);
@@ -634,7 +659,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   tb_static_for<0, 8>([&](auto J) {
     constexpr int j = decltype(J)::value;
     const unsigned p = next_panel(std::integral_constant<int, P0 + j>{});
-    tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
+    tb_mma<8, FD>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
   });
   {
     const float inv = cst[TC_SC + 1] * (1.0f / sx);
@@ -678,7 +703,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
         constexpr int u = decltype(U)::value;
         const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + u>{});
         f32x4 ha[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        tb_mma<8>(ha[0], ha[1], p, xh, xl, fr, fg, half);
+        tb_mma<8, FD>(ha[0], ha[1], p, xh, xl, fr, fg, half);
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
           const float4 be = *reinterpret_cast<const float4*>(cst + TC_BEXP + 128 * c + 32 * u + 16 * w + 4 * fg);
@@ -702,7 +727,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
       tb_static_for<0, 8>([&](auto J) {
         constexpr int j = decltype(J)::value;
         const unsigned p = next_panel(std::integral_constant<int, P0 + 8 + 12 * c + 4 + j>{});
-        tb_mma<4>(acc[2 * j], acc[2 * j + 1], p, hh, hl, fr, fg, half);
+        tb_mma<4, FD>(acc[2 * j], acc[2 * j + 1], p, hh, hl, fr, fg, half);
       });
     });
   }
@@ -720,12 +745,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     }
     tb_layernorm(acc, cst + TC_G2, cst + TC_BE2, fg, a.eps);
   }
+  TB_ST(2);
   if (valid) {
     float* o = a.out + (size_t)row * 256;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       *reinterpret_cast<float4*>(o + 16 * i + 4 * fg) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
   }
+  TB_ST(3);
+#ifdef TB_STAMP
+  if (blockIdx.x < 512)
+    for (int i = lane; i < TB_NSTAMP; i += 64) st_base[i] = st_lds[wave][i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1002,12 +1033,13 @@ extern "C" int sam6d_linattn_layer(const float* D, const void* wimage, const flo
   if (B == 0) return 0;
   int rc = tb_set_attr();
   if (rc) return rc;
-  const int tok = tb_shape() == 8 ? 128 : 64;  // tokens per workgroup of the kernel shape launched below
+  const int dshape = tb_shape() == 8 ? 8 : 4;  // (128-token workgroups for the dense layer alone: 0.342 ms against 0.341 ms)
+  const int tok = dshape == 8 ? 128 : 64;  // tokens per workgroup of the kernel shape launched below
   const int tiles = (I - row0 + tok - 1) / tok;
   SAM6D_REQUIRE((long)B * tiles < 2147483647L, "linattn_layer: too many tiles");
   TbArgs a{D, nullptr, Dout, (const unsigned char*)wimage, consts, (const unsigned char*)kvimage, kvinv, ksum, 0, I, row0, tiles, eps,
            sam6d_half_for(1)};
-  if (tb_shape() == 8)
+  if (dshape == 8)
     hipLaunchKernelGGL((token_block_kernel<1, 8, 4>), dim3((unsigned)(B * tiles)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((token_block_kernel<1, 4, 2>), dim3((unsigned)(B * tiles)), dim3(256), TB_LDS_BYTES(2), (hipStream_t)stream, a);

@@ -316,9 +316,25 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
   }
 }
 
+// max_wg: upper bound on the persistent workgroups of the split-precision kernel (0 = fill the chip: 768 = 3 per CU).  A launch that
+// shares the chip with another stream's kernels leaves room with 256 or 512 (1 or 2 per CU: 49 / 97 KB of LDS, 150 / 300 VGPRs per SIMD).
+static int pe_mlp_max_impl(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1, const float* sh1,
+                           const float* W2, const float* sc2, const float* sh2, const float* W3, const float* sc3, const float* sh3,
+                           float* out, long ldo, int off, int max_wg, void* stream);
 extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
                                 const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
                                 const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream) {
+  return pe_mlp_max_impl(pts, idx, B, N, S, W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off, 0, stream);
+}
+extern "C" int sam6d_pe_mlp_max_wg(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
+                                   const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
+                                   const float* sc3, const float* sh3, float* out, long ldo, int off, int max_wg, void* stream) {
+  SAM6D_REQUIRE(max_wg >= 0, "pe_mlp_max_wg: max_wg must be >= 0");
+  return pe_mlp_max_impl(pts, idx, B, N, S, W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off, max_wg, stream);
+}
+static int pe_mlp_max_impl(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1, const float* sh1,
+                           const float* W2, const float* sc2, const float* sh2, const float* W3, const float* sc3, const float* sh3,
+                           float* out, long ldo, int off, int max_wg, void* stream) {
   SAM6D_REQUIRE(pts && idx && W1 && sc1 && sh1 && W2 && sc2 && sh2 && W3 && sc3 && sh3 && out, "pe_mlp_max: null pointer");
   SAM6D_REQUIRE(B >= 0 && N > 0 && S > 0 && (S & 31) == 0, "pe_mlp_max: nsample must be a multiple of 32 (got %d)", S);
   const long total = (long)B * N;
@@ -340,7 +356,8 @@ extern "C" int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, 
     }
     // persistent waves: 3 workgroups of 4 waves fit one CU's LDS (3 x 48.6 KB) -> 768 workgroups fill the 256 CUs once
     const long want = (total + PH_WAVES - 1) / PH_WAVES;
-    const dim3 pgrid((unsigned)(want < 768 ? want : 768));
+    const long cap = (max_wg > 0 && max_wg < 768) ? max_wg : 768;
+    const dim3 pgrid((unsigned)(want < cap ? want : cap));
     hipLaunchKernelGGL(pe_mlp_max_h3_kernel, pgrid, dim3(PH_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, (int)total,
                        W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
   } else {

@@ -254,7 +254,7 @@ extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int
   if (B == 0 || m == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)((N * 3 + 3) & ~3) * 4 + 2 * 16 * 8;
-  if (N <= 512 * 4) {
+  if (N <= 512 * 4) {  // (256 threads x 8 points per lane -- 4 waves, a cheaper barrier -- was measured: 179 us against 160 us)
     hipLaunchKernelGGL((fps_reg_kernel<512, 4>), dim3(B), dim3(512), lds, s, xyz, N, m, idx);
   } else if (N <= 1024 * 4) {  // 48 KB of LDS points: stays under the 64 KB dynamic-LDS default
     hipLaunchKernelGGL((fps_reg_kernel<1024, 4>), dim3(B), dim3(1024), lds, s, xyz, N, m, idx);

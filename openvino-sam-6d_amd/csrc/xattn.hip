@@ -51,22 +51,52 @@ __device__ __forceinline__ float xa_tok_sum(float s) {
 
 // acc (16 out rows x 16 tokens) += W[rows r0 .. r0+16) . X over KS k-steps.  Image rows are ROWB bytes: hi plane then lo plane (LOCH
 // 16-byte chunks further), chunk c stored at (c & ~15) | ((c ^ row) & 15).
+// The fragment reads run XA_FD steps ahead of the MFMAs, as inline assembly with counted waits (block.hip tb_mma does the same): left
+// to the compiler every ds_read_b128 sinks to just before its use behind an lgkmcnt(0), and with three MFMAs (48 cycles) per step the
+// LDS latency (~150 cycles) was exposed on every one of a wave's ~300 steps -- half of the kernel (SQ_WAIT_ANY 52 % of the wave cycles).
+typedef unsigned xa_u32x4 __attribute__((ext_vector_type(4)));
+#define XA_FD 4
+__device__ __forceinline__ xa_u32x4 xa_lds128(unsigned addr) {
+  xa_u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void xa_wait(xa_u32x4& a, xa_u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int ROWB, int LOCH, int KS, int S>
+__device__ __forceinline__ void xa_mma_step(f32x4& acc, unsigned rb, int row, int fg, const half8* __restrict__ xh,
+                                            const half8* __restrict__ xl, xa_u32x4 (&fh)[XA_FD + 1], xa_u32x4 (&fl)[XA_FD + 1], bool half) {
+  if constexpr (S + XA_FD < KS) {
+    const int ch = 4 * (S + XA_FD) + fg, cl = LOCH + 4 * (S + XA_FD) + fg;
+    fh[(S + XA_FD) % (XA_FD + 1)] = xa_lds128(rb + (((ch & ~15) | ((ch ^ row) & 15)) << 4));
+    fl[(S + XA_FD) % (XA_FD + 1)] = xa_lds128(rb + (((cl & ~15) | ((cl ^ row) & 15)) << 4));
+  }
+  constexpr int newer = (KS - 1 - S) < XA_FD ? (KS - 1 - S) : XA_FD;
+  constexpr int cur = S % (XA_FD + 1);
+  xa_wait<2 * newer>(fh[cur], fl[cur]);
+  const half8 ah = __builtin_bit_cast(half8, fh[cur]), al = __builtin_bit_cast(half8, fl[cur]);
+  if (!half) {  // (launch-uniform) matmul mode 2 keeps the hi . hi product only
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[S], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[S], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[S], acc, 0, 0, 0);
+  if constexpr (S + 1 < KS) xa_mma_step<ROWB, LOCH, KS, S + 1>(acc, rb, row, fg, xh, xl, fh, fl, half);
+}
 template <int ROWB, int LOCH, int KS>
 __device__ __forceinline__ void xa_mma(f32x4& acc, const unsigned char* __restrict__ img, int r0, const half8* __restrict__ xh,
                                        const half8* __restrict__ xl, int fr, int fg, bool half) {
   const int row = r0 + fr;
-  const unsigned char* rb = img + (size_t)row * ROWB;
+  const unsigned rb = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)img + (unsigned)row * ROWB;
+  xa_u32x4 fh[XA_FD + 1], fl[XA_FD + 1];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
+  for (int s = 0; s < XA_FD && s < KS; ++s) {
     const int ch = 4 * s + fg, cl = LOCH + 4 * s + fg;
-    const half8 ah = *reinterpret_cast<const half8*>(rb + (((ch & ~15) | ((ch ^ row) & 15)) << 4));
-    const half8 al = *reinterpret_cast<const half8*>(rb + (((cl & ~15) | ((cl ^ row) & 15)) << 4));
-    if (!half) {  // (launch-uniform) matmul mode 2 keeps the hi . hi product only
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[s], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[s], acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[s], acc, 0, 0, 0);
+    fh[s] = xa_lds128(rb + (((ch & ~15) | ((ch ^ row) & 15)) << 4));
+    fl[s] = xa_lds128(rb + (((cl & ~15) | ((cl ^ row) & 15)) << 4));
   }
+  xa_mma_step<ROWB, LOCH, KS, 0>(acc, rb, row, fg, xh, xl, fh, fl, half);
 }
 
 struct XaArgs {

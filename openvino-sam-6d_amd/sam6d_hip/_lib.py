@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsam6d_hip.so")
+LIB_PATH = os.environ.get("SAM6D_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libsam6d_hip.so")  # (SAM6D_LIB: a diagnostic build)
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -48,6 +48,7 @@ SIGNATURES = {
     "sam6d_linattn_kv": [c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_p, c_p, c_p],
     "sam6d_linattn_focus_q": [c_p, c_p, c_p, c_i, c_l, c_l, c_p],
     "sam6d_pe_mlp_max": [c_p, c_p, c_i, c_i, c_i] + [c_p] * 10 + [c_l, c_i, c_p],
+    "sam6d_pe_mlp_max_wg": [c_p, c_p, c_i, c_i, c_i] + [c_p] * 10 + [c_l, c_i, c_i, c_p],
     "sam6d_rigid_inverse": [c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "sam6d_put_rows": [c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p],
     "sam6d_prepend_bg_point": [c_p, c_i, c_i, c_p, c_p],

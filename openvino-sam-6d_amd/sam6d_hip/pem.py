@@ -643,8 +643,8 @@ def _rpe_self_tail(x, x2, G, L, qkv, qp, qd, vT=None):
     M = Bp * n
     ldp = (n + 3) // 4 * 4
     qk = _empty((M, H, ldp), x)
-    gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
     P = _empty((M, H, ldp), x)
+    gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
     with _Timed("rpe_score_kernel"):
         _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd),
                   _p(qk), _p(P), M, n, ldp, _s())
@@ -855,16 +855,17 @@ def pe_group(pts, r1=0.1, r2=0.2, ns1=32, ns2=64):
     return idx12
 
 
-def pe_apply(pts, idx12, W, dst, dst_off, dst_sb):
-    """dst rows += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2))) for the groups of pe_group."""
+def pe_apply(pts, idx12, W, dst, dst_off, dst_sb, max_wg=0):
+    """dst rows += mlp3(cat(max_s mlp1(group_r1), max_s mlp2(group_r2))) for the groups of pe_group.  max_wg: bound on the persistent
+    workgroups of the MLP kernels (0 = fill the chip) for launches that share the chip with another stream."""
     Bp, N, _ = pts.shape
     feat = _empty((Bp * N, 2 * 128), pts)
     for k in range(2):
         idx = idx12[k]
         L = W.pe["mlp"][k]
-        _lib.call("sam6d_pe_mlp_max", _p(pts), _p(idx), Bp, N, idx.shape[2], _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
+        _lib.call("sam6d_pe_mlp_max_wg", _p(pts), _p(idx), Bp, N, idx.shape[2], _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
                   _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),
-                  _p(feat), 2 * 128, k * 128, _s())
+                  _p(feat), 2 * 128, k * 128, int(max_wg), _s())
     m3 = W.pe["mlp3"]
     gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
          sC=dst_sb, sR=dst_sb, w16=m3.w16())
@@ -1107,16 +1108,16 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
     return D, grp
 
 
-def fine_static_b(dp, D, grp, W, shared_template=False):
+def fine_static_b(dp, D, grp, W, shared_template=False, max_wg=0):
     """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run).
     shared_template: one cloud's worth, then the finished token block of slot B is copied to the other template slots."""
     Bp, N, _ = dp.shape
     B = Bp // 2
     if shared_template and B > 1:
-        pe_apply(dp[B:B + 1], grp, W, D, B * (N + 1) * C + C, (N + 1) * C)
+        pe_apply(dp[B:B + 1], grp, W, D, B * (N + 1) * C + C, (N + 1) * C, max_wg)
         _lib.call("sam6d_put_rows", _p(D, B * (N + 1) * C), 0, C, _p(D, (B + 1) * (N + 1) * C), (N + 1) * C, C, B - 1, N + 1, C, _s())
         return D
-    pe_apply(dp[B:], grp, W, D, B * (N + 1) * C + C, (N + 1) * C)
+    pe_apply(dp[B:], grp, W, D, B * (N + 1) * C + C, (N + 1) * C, max_wg)
     return D
 
 
@@ -1292,7 +1293,7 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
                 ev.record(cur)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    fine_static_b(dp, D, grp, W, shared_template)
+                    fine_static_b(dp, D, grp, W, shared_template, max_wg=int(os.environ.get("SAM6D_PE_SIDE_WGS", "512")))
         elif overlap:
             D, side = fork_fine_static(dp, df, side_key)
         c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux, before_pose=hook)
