@@ -131,7 +131,8 @@ int sam6d_gemm_ln256(const float* A, const float* W, const float* bias, const fl
  *     y = LayerNorm(hidden . Wlin^T + b + x);  out = LayerNorm(relu(y . Wexp^T + b) . Wsq^T + b + y)        all (M,256)
  * sam6d_linattn_layer: the whole LinearTransformerLayer of the dense lift (PEM/model/transformer.py:532-622) on rows row0 .. I-1 of
  *   each of the B clouds of D (B,I,256): proj_q, focused kernel function, z, (phi(q) kv) z per head, then the tail above with x = D.
- *   kvimage / kvinv: sam6d_linattn_kv_pack of the (B,4,64,64) kv^T that sam6d_linattn_kv returns; ksum (B,256) its key sums.
+ *   kvimage / kvinv: sam6d_linattn_kv_pack of the (B,4,64,64) kv^T that sam6d_linattn_kv returns -- kvinv (B,4): the inverse
+ *   power-of-two image scale of every head; ksum (B,256) its key sums.
  * wimage: the layer's weights as the kernels' LDS panel image (sam6d_token_block_image_bytes(mode) bytes, mode 1 = with proj_q),
  *   written by sam6d_pack_panels: rows x K fp32 -> 32-row panels of fp16 hi/lo halves, K in `ksteps` steps of 16 from column k0,
  *   values multiplied by `scale` (a power of two).  Image order: linear (8 panels, K=256) | 4 x { expand rows 128c.. (4 panels,

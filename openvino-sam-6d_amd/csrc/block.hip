@@ -109,31 +109,39 @@ __device__ __forceinline__ float pow2_scale_for(float amax) {
   return ldexpf(1.0f, e);
 }
 
-// per cloud: kv^T (4 heads x 64 d x 64 c) -> 8 panels of 32 d-rows x K = 64 (head h: panels 2h, 2h+1), scaled by a power of two
-// chosen from the cloud's max |kv|; inv[b] = 1 / scale.
+// per cloud: kv^T (4 heads x 64 d x 64 c) -> 8 panels of 32 d-rows x K = 64 (head h: panels 2h, 2h+1), every head scaled by its own
+// power of two (from the head's max |kv|); inv[4 b + h] = 1 / scale.
 __global__ __launch_bounds__(256) void tb_kv_pack_kernel(const float* __restrict__ kvT, unsigned char* __restrict__ dst,
                                                          float* __restrict__ inv) {
-  __shared__ float red[4];
+  __shared__ float red[4][4];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* src = kvT + (size_t)b * 16384;
-  float m = 0.f;
-  for (int i = t; i < 16384; i += 256) m = fmaxf(m, fabsf(src[i]));
-  m = wave_max_dpp(m);
-  if ((t & 63) == 0) red[t >> 6] = m;
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd)
+    for (int i = t; i < 4096; i += 256) m[hd] = fmaxf(m[hd], fabsf(src[hd * 4096 + i]));
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) {
+    m[hd] = wave_max_dpp(m[hd]);
+    if ((t & 63) == 0) red[hd][t >> 6] = m[hd];
+  }
   __syncthreads();
-  const float scale = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-  if (t == 0) inv[b] = 1.0f / scale;
+  float scale[4];
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) scale[hd] = pow2_scale_for(fmaxf(fmaxf(red[hd][0], red[hd][1]), fmaxf(red[hd][2], red[hd][3])));
+  if (t < 4) inv[(size_t)b * 4 + t] = 1.0f / (t == 0 ? scale[0] : t == 1 ? scale[1] : t == 2 ? scale[2] : scale[3]);
   unsigned char* out = dst + (size_t)b * (8 * TB_P64);
   for (int i = t; i < 16384; i += 256) {
     const int hd = i >> 12, d = (i >> 6) & 63, p = i & 63;  // p: slot inside the 64-wide K
     const int c = 32 * (p >> 5) + tb_slot_channel(p & 31);
-    const float v = src[(hd * 64 + d) * 64 + c] * scale;
+    const float sc = hd == 0 ? scale[0] : hd == 1 ? scale[1] : hd == 2 ? scale[2] : scale[3];
+    const float v = src[(hd * 64 + d) * 64 + c] * sc;
     _Float16 hi, lo;
     sam6d_split_f16(v, hi, lo);
-    const int m = d & 31;
-    _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)(2 * hd + (d >> 5)) * TB_P64 + (size_t)m * TB_ROWB(2));
-    row[(((p >> 3) ^ (m & 15)) << 3) + (p & 7)] = hi;
-    row[((((64 + p) >> 3) ^ (m & 15)) << 3) + (p & 7)] = lo;
+    const int mrow = d & 31;
+    _Float16* row = reinterpret_cast<_Float16*>(out + (size_t)(2 * hd + (d >> 5)) * TB_P64 + (size_t)mrow * TB_ROWB(2));
+    row[(((p >> 3) ^ (mrow & 15)) << 3) + (p & 7)] = hi;
+    row[((((64 + p) >> 3) ^ (mrow & 15)) << 3) + (p & 7)] = lo;
   }
 }
 
@@ -146,29 +154,50 @@ __global__ __launch_bounds__(256) void tb_kv_pack_kernel(const float* __restrict
 // accumulates over the keys in ascending order, exactly as kv_reduce_kernel does.
 __device__ __forceinline__ float tbk_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-__global__ __launch_bounds__(1024) void tb_kv_fused_kernel(const float* __restrict__ kv, const float* __restrict__ scale, int J, long ld,
-                                                           long sb, unsigned char* __restrict__ image, float* __restrict__ inv,
-                                                           float* __restrict__ ksum) {
-  __shared__ float ks[16][256];
-  __shared__ float vs[16][260];
-  __shared__ float red[16];
-  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// Round 3: one workgroup per (cloud, HEAD) instead of per cloud (64 workgroups of 1024 threads on 64 of the 256 CUs, 68 us): 256
+// threads own kv^T[h][d][c0 .. c0 + 15] of their head, the four waves stage the 16 key rows of a step (a wave = one 256-channel row:
+// the focus norms need the whole row, only the head's 64 k and 64 v channels go to LDS), every head gets its own power-of-two scale.
+// Same phi(k), same per-output accumulation order: kv^T and the key sums keep their bits.
+__global__ __launch_bounds__(256) void tb_kv_fused_kernel(const float* __restrict__ kv, const float* __restrict__ scale, int J, long ld,
+                                                          long sb, unsigned char* __restrict__ image, float* __restrict__ inv,
+                                                          float* __restrict__ ksum) {
+  __shared__ float ks[16][64];
+  __shared__ float vs[16][68];
+  __shared__ float red[4];
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* kb = kv + (size_t)b * sb;
   const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
   const float sp[4] = {tbk_softplus(sc.x), tbk_softplus(sc.y), tbk_softplus(sc.z), tbk_softplus(sc.w)};
-  const int h = t >> 8, d = (t >> 2) & 63, c0 = (t & 3) * 16;
+  const int d = t >> 2, c0 = (t & 3) * 16;
+  const bool mine = (lane >> 4) == h;  // this lane's 4 channels belong to head h
   float acc[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-  float ksacc = 0.f;  // threads with (t & 255) < 64 accumulate ksum[h][c = t & 63]
+  float ksacc = 0.f;  // threads t < 64 accumulate ksum[h][c = t]
+  // this wave's four key rows of a step (rows wave, wave + 4, ...): all eight loads in flight at once, and the NEXT step's rows are
+  // requested before this step's accumulation (the loop was a chain of load round trips: 63 us for 13 steps)
+  float4 xr[4], vr[4];
+  auto fetch = [&](int j0) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = j0 + 4 * rr + wave;
+      xr[rr] = vr[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < J) {
+        xr[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + lane * 4);
+        vr[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + 256 + lane * 4);
+      }
+    }
+  };
+  fetch(0);
   for (int j0 = 0; j0 < J; j0 += 16) {
     __syncthreads();
-    {
-      const int j = j0 + wave;  // one key row per wave
-      float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int jr = 4 * rr + wave, j = j0 + jr;
+      float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vx = vr[rr];
       if (j < J) {
-        const float4 x = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + lane * 4);
-        vx = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + 256 + lane * 4);
+        const float4 x = xr[rr];
         float a[4] = {x.x, x.y, x.z, x.w}, c[4];
         float n1 = 0.f, n3 = 0.f;
 #pragma unroll
@@ -183,31 +212,31 @@ __global__ __launch_bounds__(1024) void tb_kv_fused_kernel(const float* __restri
         n3 = sqrtf(wave_sum_dpp(n3));
         kx = make_float4((c[0] / n3) * n1, (c[1] / n3) * n1, (c[2] / n3) * n1, (c[3] / n3) * n1);
       }
-      *reinterpret_cast<float4*>(&ks[wave][lane * 4]) = kx;
-      *reinterpret_cast<float4*>(&vs[wave][lane * 4]) = vx;
+      if (mine) {
+        *reinterpret_cast<float4*>(&ks[jr][(lane & 15) * 4]) = kx;
+        *reinterpret_cast<float4*>(&vs[jr][(lane & 15) * 4]) = vx;
+      }
     }
     __syncthreads();
+    if (j0 + 16 < J) fetch(j0 + 16);
 #pragma unroll 4
     for (int jj = 0; jj < 16; ++jj) {
-      const float vv = vs[jj][h * 64 + d];
+      const float vv = vs[jj][d];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] = fmaf(ks[jj][h * 64 + c0 + u], vv, acc[u]);
-      if ((t & 255) < 64) ksacc += ks[jj][h * 64 + (t & 63)];
+      for (int u = 0; u < 16; ++u) acc[u] = fmaf(ks[jj][c0 + u], vv, acc[u]);
+      if (t < 64) ksacc += ks[jj][t];
     }
   }
-  if ((t & 255) < 64) ksum[((size_t)b * 4 + h) * 64 + (t & 63)] = ksacc;
-  // the cloud's scale from max |kv^T| (all four heads)
+  if (t < 64) ksum[((size_t)b * 4 + h) * 64 + t] = ksacc;
+  // the head's scale from max |kv^T_h|
   float m = 0.f;
 #pragma unroll
   for (int u = 0; u < 16; ++u) m = fmaxf(m, fabsf(acc[u]));
   m = wave_max_dpp(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  float mm = red[0];
-#pragma unroll
-  for (int w = 1; w < 16; ++w) mm = fmaxf(mm, red[w]);
-  const float s2 = pow2_scale_for(mm);
-  if (t == 0) inv[b] = 1.0f / s2;
+  const float s2 = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  if (t == 0) inv[(size_t)b * 4 + h] = 1.0f / s2;
   // image: head h, row d -> panel 2 h + (d >> 5), row m = d & 31; channel c sits in slot p = 32 (c >> 5) + 8 g + e of the 64-wide K
   // (tb_slot_channel inverted: g = (c >> 2) & 3, e = 4 ((c >> 4) & 1) + (c & 3))
   const int mrow = d & 31;
@@ -235,7 +264,7 @@ extern "C" int sam6d_linattn_kv_image(const float* kv, const float* scale, int B
                     (((size_t)kv | (size_t)scale) & 15) == 0,
                 "linattn_kv_image: bad arguments (kv rows = 256 k | 256 v channels, 16-byte aligned)");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(tb_kv_fused_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
+  hipLaunchKernelGGL(tb_kv_fused_kernel, dim3(4, B), dim3(256), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
                      (unsigned char*)image, inv, ksum);
   SAM6D_LAUNCH_CHECK("linattn_kv_image");
 }
@@ -401,7 +430,7 @@ struct TbArgs {
   const unsigned char* wimg;
   const float* consts;
   const unsigned char* kvimg;  // mode 1: (B, 8 panels)
-  const float* kvinv;          // mode 1: (B)
+  const float* kvinv;          // mode 1: (B, 4) one inverse image scale per head
   const float* ksum;           // mode 1: (B, 256)
   long M;                 // mode 0: rows
   int I, row0, tiles_per_b;  // mode 1: rows per cloud, first row handled, tiles per cloud
@@ -544,8 +573,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     float4 va[8], vb[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
-      vb[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+      if constexpr (MODE != 0) {
+        // the dense layer streams 134 MB of tokens in and out once: non-temporal, so that they do not evict the weight / kv images that
+        // 2048 workgroups re-read from the L2 (FETCH_SIZE: 237 MB for 140 MB of compulsory reads with ordinary loads)
+        const f32x4 x0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 32 * s + 4 * fg));
+        const f32x4 x1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 32 * s + 16 + 4 * fg));
+        va[s] = make_float4(x0[0], x0[1], x0[2], x0[3]);
+        vb[s] = make_float4(x1[0], x1[1], x1[2], x1[3]);
+      } else {
+        va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
+        vb[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+      }
     }
     float m = 0.f;
 #pragma unroll
@@ -645,9 +683,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
       tb_mma<2, FD>(acc[2 * j], acc[2 * j + 1], p, xh + 2 * (j >> 1), xl + 2 * (j >> 1), fr, fg, half);
     });
     {
-      const float inv = a.kvinv[b] * (1.0f / sx);
+      const float4 kvi = *reinterpret_cast<const float4*>(a.kvinv + (size_t)b * 4);  // the four heads' image scales
+      const float isx = 1.0f / sx;
+      const float invh[4] = {kvi.x * isx, kvi.y * isx, kvi.z * isx, kvi.w * isx};
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        const float inv = invh[i >> 2];  // accumulator tiles 4 h .. 4 h + 3 hold head h's 64 channels
         acc[i][0] *= inv; acc[i][1] *= inv; acc[i][2] *= inv; acc[i][3] *= inv;
       }
       sx = tb_split_rows<16>(acc, xh, xl);
@@ -749,8 +790,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   if (valid) {
     float* o = a.out + (size_t)row * 256;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      *reinterpret_cast<float4*>(o + 16 * i + 4 * fg) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    for (int i = 0; i < 16; ++i) {
+      if constexpr (MODE != 0) __builtin_nontemporal_store(acc[i], reinterpret_cast<f32x4*>(o + 16 * i + 4 * fg));
+      else *reinterpret_cast<float4*>(o + 16 * i + 4 * fg) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    }
   }
   TB_ST(3);
 #ifdef TB_STAMP

@@ -802,7 +802,7 @@ def linear_transformer_layer(D, S, L):
         # the whole layer on the dense tokens (rows 1 .. I-1 of every cloud) in one launch; row 0 (the bg slot) is written by the caller
         tb = L["tbd"]
         kvimg = torch.empty(Bp * TB_P64 * 8, dtype=torch.uint8, device=D.device)
-        kvinv = _empty((Bp,), D)
+        kvinv = _empty((Bp, 4), D)  # one image scale per head
         # phi(k), kv^T, the key sums and the packed fp16 image of kv^T in one launch (was focus_k + kv + kv_pack)
         _lib.call("sam6d_linattn_kv_image", _p(kv), _p(L["scale"]), Bp, J, 2 * C, J * 2 * C, kvimg.data_ptr(), _p(kvinv), _p(ksum), _s())
         Dn = _empty((Bp, I, C), D)
@@ -1192,7 +1192,8 @@ def _side_stream(dev, key=0):
     streams and ("mb", i, "side") their side streams)."""
     s = _SIDE_STREAMS.get((dev, key))
     if s is None:
-        s = _SIDE_STREAMS[(dev, key)] = torch.cuda.Stream(device=dev)
+        prio = os.environ.get("SAM6D_SIDE_PRIO")  # A/B: HIP stream priority of the auxiliary streams (default: the default priority)
+        s = _SIDE_STREAMS[(dev, key)] = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
     return s
 
 

@@ -85,7 +85,7 @@ def test_linattn_kv_image_equals_three_launches(dev, Bp, J):
     kv = (torch.randn(Bp, J, 512, generator=gen) * 1.7).to(dev).contiguous()
     scale = (0.3 * torch.randn(256, generator=gen)).to(dev)
     nb = int(_lib.load().sam6d_linattn_kv_image_bytes())
-    img1 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv1 = torch.zeros(Bp, device=dev); ks1 = torch.zeros(Bp, 4, 64, device=dev)
+    img1 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv1 = torch.zeros(Bp, 4, device=dev); ks1 = torch.zeros(Bp, 4, 64, device=dev)
     kv_in = kv.clone()
     _lib.call("sam6d_linattn_kv_image", pem._p(kv), pem._p(scale), Bp, J, 512, J * 512, img1.data_ptr(), pem._p(inv1), pem._p(ks1), pem._s())
     assert torch.equal(kv, kv_in)
@@ -93,11 +93,12 @@ def test_linattn_kv_image_equals_three_launches(dev, Bp, J):
     _lib.call("sam6d_linattn_focus_k", pem._p(k2), pem._p(scale), Bp * J, 512, pem._s())
     kvT = torch.zeros(Bp, 4, 64, 64, device=dev); ks2 = torch.zeros(Bp, 4, 64, device=dev)
     _lib.call("sam6d_linattn_kv", pem._p(k2), pem._p(k2, 256), Bp, J, 512, 512, J * 512, J * 512, pem._p(kvT), pem._p(ks2), pem._s())
-    img2 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv2 = torch.zeros(Bp, device=dev)
+    img2 = torch.zeros(Bp * nb, dtype=torch.uint8, device=dev); inv2 = torch.zeros(Bp, 4, device=dev)
     _lib.call("sam6d_linattn_kv_pack", pem._p(kvT), Bp, img2.data_ptr(), pem._p(inv2), pem._s())
     torch.cuda.synchronize()
     assert torch.equal(ks1, ks2), "key sums"
-    assert torch.equal(inv1, inv2), "image scale"
+    assert torch.equal(inv1, inv2), "image scales (one per head)"
+    assert inv1.shape == (Bp, 4) and bool((inv1 > 0).all())
     assert torch.equal(img1, img2), "packed kv^T image: %d bytes differ" % int((img1 != img2).sum())
 
 
