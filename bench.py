@@ -311,7 +311,7 @@ def main():
         traffic = None  # HBM bytes per launch from the PMC passes recorded under profiles/ (not measured live)
         tj = {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
             traffic = tj["kernels"][kname if fused else "geo_embed_h3_kernel"]["hbm_bytes_per_launch"] if B == B_PER_GPU else None
             if traffic is not None and fused:  # recorded for a 64-cloud launch; a micro-batch slice moves its share
                 mbk = int(os.environ.get("SAM6D_MICROBATCH", "1"))
