@@ -210,11 +210,21 @@ int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void* w_cheb, fl
  *   image; qd[q][h][0..32) = D_c^T qp[q][h], D_c = Chebyshev coefficients of proj_d) or read from `rows` for listed pairs.
  *   qp (Q,4,256) = proj_p folded into the query (see sam6d_attention), qk (Q,4,ldp) = q_h . k_h[m]; qk is updated in place
  *   (the geometric term of the listed pairs is added to it first, one wave per pair of list_ws).
- * sam6d_transpose: dst[b][c][j] = src[b][j][c] (the values as the N x K operand of the P.V GEMM). */
+ * sam6d_transpose: dst[b][c][j] = src[b][j][c] (the values as the N x K operand of the P.V GEMM).
+ * sam6d_geo_outliers2 / sam6d_rpe_scores2: the same two steps with a range of their own for the three angular indices
+ *   ([0, xmax_a]; the angle of GeometricStructureEmbedding.get_embedding_indices, transformer.py:326-341, times 180 / (sigma_a pi) never
+ *   exceeds 180 / sigma_a = 12) -- wa_cheb then holds proj_a's expansion on [0, xmax_a] -- and `products` = 3 (every split product over
+ *   all 32 orders) or 2 (the cross terms of the orders 0..15 in one MFMA, those of the orders >= 16 dropped: the caller guarantees
+ *   that 2^-10 sum_{p >= 16} |c[ch][p]| is negligible for every channel).  The entries without the suffix = xmax_a = xmax, products = 3. */
 int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, const float* div_term, const void* w_packed, const float* Wd,
                        const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows, void* stream);
 int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb, float xmax,
                      const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp, void* stream);
+int sam6d_geo_outliers2(const float* idx_ws, long pairs, float xmax, float xmax_a, const float* div_term, const void* w_packed,
+                        const float* Wd, const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows, void* stream);
+int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb, float xmax,
+                      float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp,
+                      void* stream);
 int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n, int ncol, float* dst, long ld_dst,
                     long stride_dst, void* stream);
 

@@ -399,7 +399,7 @@ __global__ void geo_list_reset_kernel(int* __restrict__ list) { list[0] = 0; }
 // pair into every 197-pair row).  The order of the list entries is arbitrary; consumers address rows through pos[].
 #define GCL_PPT 16
 #define GCL_PER (256 * GCL_PPT)
-__global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax,
+__global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restrict__ idx4, long total, float xmax, float xmax_a,
                                                            int* __restrict__ pos, int* __restrict__ list) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
@@ -411,7 +411,8 @@ __global__ __launch_bounds__(256) void geo_classify_kernel(const float4* __restr
     const long e = e0 + (long)i * 256;
     if (e < total) {
       const float4 v = idx4[e];
-      const bool ok = v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax && v.z >= 0.f && v.z <= xmax && v.w >= 0.f && v.w <= xmax;
+      const bool ok = v.x >= 0.f && v.x <= xmax && v.y >= 0.f && v.y <= xmax_a && v.z >= 0.f && v.z <= xmax_a && v.w >= 0.f &&
+                      v.w <= xmax_a;  // x: the distance index, y z w: the angular ones
       if (!ok) out_mask |= 1u << i;
     }
   }
@@ -608,7 +609,7 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,
-                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
+                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, xmax, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb(classify)");
   const long ntiles = (pairs + GH_P - 1) / GH_P;
   hipLaunchKernelGGL(geo_cheb_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(512), GC_LDS_BYTES, s,
@@ -628,15 +629,21 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
 extern "C" int sam6d_geo_outliers(const float* idx_ws, long pairs, float xmax, const float* div_term, const void* w_packed,
                                   const float* Wd, const float* Wa, const int* flag, int* pos_ws, int* list_ws, float* rows,
                                   void* stream) {
+  return sam6d_geo_outliers2(idx_ws, pairs, xmax, xmax, div_term, w_packed, Wd, Wa, flag, pos_ws, list_ws, rows, stream);
+}
+
+extern "C" int sam6d_geo_outliers2(const float* idx_ws, long pairs, float xmax, float xmax_a, const float* div_term,
+                                   const void* w_packed, const float* Wd, const float* Wa, const int* flag, int* pos_ws, int* list_ws,
+                                   float* rows, void* stream) {
   SAM6D_REQUIRE(idx_ws && div_term && w_packed && Wd && Wa && flag && pos_ws && list_ws && rows, "geo_outliers: null pointer");
-  SAM6D_REQUIRE(pairs >= 0 && pairs < 2147483647L && xmax > 0.f, "geo_outliers: bad sizes");
+  SAM6D_REQUIRE(pairs >= 0 && pairs < 2147483647L && xmax > 0.f && xmax_a > 0.f, "geo_outliers: bad sizes");
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)w_packed | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_outliers: 16-byte alignment");
   if (pairs == 0) return 0;
   if (int rc = h3_reserve_lds()) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(geo_list_reset_kernel, dim3(1), dim3(1), 0, s, list_ws);
   hipLaunchKernelGGL(geo_classify_kernel, dim3((unsigned)((pairs + GCL_PER - 1) / GCL_PER)), dim3(256), 0, s,
-                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, pos_ws, list_ws);
+                     reinterpret_cast<const float4*>(idx_ws), pairs, xmax, xmax_a, pos_ws, list_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_outliers(classify)");
   // rows of the listed pairs, bias-free, compact.  The grid covers the worst case (every pair listed); workgroups beyond
   // the device-side count return at once.  Default: fp16x3 sinusoid kernel; *flag != 0: the exact sincosf kernel.

@@ -116,11 +116,17 @@ extern "C" int sam6d_rpe_debug_phases(void* dst) {
 #define RP_PH(i)
 #endif
 
+// NP = split products of stage 1.  3: c_hi.t_lo + c_lo.t_hi + c_hi.t_hi, each over all 32 orders.  2: c_hi.t_hi over all 32 orders and
+// ONE MFMA for both cross terms of the orders 0..15 (A = [c_lo 0..15 | c_hi 0..15], B = [t_hi 0..15 | t_lo 0..15]: the same image
+// read with another per-lane address, the basis fragment one v_permlane32_swap per register) -- the cross terms of the orders >= 16
+// are dropped, which the host allows when 2^-10 sum_{p >= 16} |c[ch][p]| is below 3e-8 of the channel's bound (pem.py
+// geo_cheb_a_packed: the angular indices live on [0, 12.125], where the coefficients of order 16 are ~1e-6 of the leading ones).
+template <int NP>
 __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict__ idx4, const int* __restrict__ pos,
                                                          const float* __restrict__ rows, const unsigned char* __restrict__ Wc,
                                                          const float* __restrict__ qp, const float* __restrict__ qd,
                                                          const float* __restrict__ Se, float* __restrict__ P, int n, int ldp,
-                                                         long Q, float xmax, float scale, int mpad) {
+                                                         long Q, float xmax_d, float xmax_a, float scale, int mpad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* Aw = lds_raw;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -144,9 +150,12 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
   for (int i = t; i < RP_WBYTES / 16; i += blockDim.x) reinterpret_cast<uint4*>(Aw)[i] = reinterpret_cast<const uint4*>(Wc)[i];
   __syncthreads();
   RP_ST(1);
+  const float xmax = kg == 0 ? xmax_d : xmax_a;  // lane row 0 carries the distance index, rows 1..3 the angular ones
   const float uscale = 2.0f / xmax;
   const int ntiles = (n + 15) >> 4;
   const unsigned char* wbase = Aw + (size_t)kx * RP_ROW + kg * 16;
+  // second fragment of a block: the lo plane (NP = 3) or the cross-term fragment [lo 0..15 | hi 0..15] (NP = 2)
+  const unsigned char* wsec = NP == 3 ? wbase + 64 : Aw + (size_t)kx * RP_ROW + (kg < 2 ? 64 + kg * 16 : (kg - 2) * 16);
   const unsigned char* qfl = qf + (kg * 4 + (kx & 3)) * 16;  // this lane's stage-2 B fragment of 32-block G: + 256 G (+ 2048: lo)
   // Queries are dealt to workgroups round-robin (q % grid) and, inside the workgroup, taken from an LDS counter by whichever wave
   // is free: the SIMD arbitrates its three waves by age, the oldest runs a query in 90 k cycles while the youngest needs 300 k
@@ -281,13 +290,21 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       }
 
       // ---- basis fragments of the three angular rows (k = 8 kg + j, column = key kx), fp16 hi / lo
-      half8 ah[3], al[3];
+      half8 ah[3], al[3];  // NP = 2: al = the cross-term fragment (lanes 0-31: hi of the orders 0..15, lanes 32-63: their lo)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         unsigned h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) rp_split2(R[k + 1][2 * j], R[k + 1][2 * j + 1], h[j], l[j]);
         ah[k] = rp_h8(h[0], h[1], h[2], h[3]);
+        if (NP == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = __uint_as_float(h[j]), y = __uint_as_float(l[j]);
+            swap32(x, y);  // x = [h.lanes 0-31, l.lanes 0-31]
+            l[j] = __float_as_uint(x);
+          }
+        }
         al[k] = rp_h8(l[0], l[1], l[2], l[3]);
       }
 
@@ -302,12 +319,14 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       f32x4 S = {0.f, 0.f, 0.f, 0.f};
       auto load_w = [&](int cb) {  // two blocks ahead of their MFMAs: the LDS latency sits under a whole block of MFMAs
         bh[cb & 1] = *reinterpret_cast<const half8*>(wbase + cb * 16 * RP_ROW);
-        bl[cb & 1] = *reinterpret_cast<const half8*>(wbase + cb * 16 * RP_ROW + 64);
+        bl[cb & 1] = *reinterpret_cast<const half8*>(wsec + cb * 16 * RP_ROW);
       };
-      auto mfma1 = [&](int cb, int i) {  // i-th of the 9 MFMAs of block cb: products hi.lo, lo.hi, hi.hi per angular row
-        const int b = cb & 1, k = i % 3, part = i / 3;
+      constexpr int NM = 3 * NP;  // stage-1 MFMAs per block
+      auto mfma1 = [&](int cb, int i) {  // i-th of the NM MFMAs of block cb: NP = 3: hi.lo, lo.hi, hi.hi per angular row; 2: cross, hi.hi
+        const int b = cb & 1, k = i % 3, part = i / 3 + (3 - NP);
         if (part == 0) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[b], al[k], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if (part == 1) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[b], ah[k], acc[b][k], 0, 0, 0);
+        if (part == 1 && NP == 3) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[b], ah[k], acc[b][k], 0, 0, 0);
+        if (part == 1 && NP == 2) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[b], al[k], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         if (part == 2) acc[b][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[b], ah[k], acc[b][k], 0, 0, 0);
       };
       auto max_row = [&](int cb, int r) {
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
       load_w(1);
       __builtin_amdgcn_s_setprio(RP_PRIO);  // a wave inside its MFMA loop outranks the waves in their VALU / memory phases
 #pragma unroll
-      for (int i = 0; i < 9; ++i) mfma1(0, i);
+      for (int i = 0; i < NM; ++i) mfma1(0, i);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 1; s <= 18; ++s) {
@@ -343,11 +362,16 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
         if (st2) load_q((s - 4) >> 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NM; ++i) {
           if (s < 16) mfma1(s, i);
-          if ((i & 1) && s - 1 < 16) max_row(s - 1, i >> 1);          // after MFMAs 1, 3, 5, 7
-          if ((i == 2 || i == 6) && s >= 2 && s - 2 < 16) split_half(s - 2, i >> 2);
-          if (st2 && i >= 6) mfma2((s - 4) >> 1, i - 6);
+          if (NP == 3) {
+            if ((i & 1) && s - 1 < 16) max_row(s - 1, i >> 1);          // after MFMAs 1, 3, 5, 7
+            if ((i == 2 || i == 6) && s >= 2 && s - 2 < 16) split_half(s - 2, i >> 2);
+          } else {
+            if ((i == 0 || i == 3) && s >= 2 && s - 2 < 16) split_half(s - 2, i / 3);
+            if (i != 0 && i != 3 && s - 1 < 16) max_row(s - 1, i - 1 - (i > 3));  // after MFMAs 1, 2, 4, 5
+          }
+          if (st2 && i >= NM - 3) mfma2((s - 4) >> 1, i - (NM - 3));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -450,7 +474,15 @@ __global__ __launch_bounds__(256) void rpe_listed_kernel(const int* __restrict__
 extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
                                 float xmax, const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp,
                                 void* stream) {
+  return sam6d_rpe_scores2(idx_ws, pos_ws, list_ws, rows, wa_cheb, xmax, xmax, 3, qp, qd, qk, P, Q, n, ldp, stream);
+}
+
+extern "C" int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
+                                 float xmax, float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q,
+                                 int n, int ldp, void* stream) {
   SAM6D_REQUIRE(idx_ws && pos_ws && list_ws && rows && wa_cheb && qp && qd && qk && P, "rpe_scores: null pointer");
+  SAM6D_REQUIRE(products == 2 || products == 3, "rpe_scores: products must be 2 or 3 (got %d)", products);
+  SAM6D_REQUIRE(xmax_a > 0.f, "rpe_scores: xmax_a must be positive");
   SAM6D_REQUIRE(Q >= 0 && n > 0 && n <= RP_MAXM && ldp >= n, "rpe_scores: need 0 < n <= %d and ldp >= n (n = %d, ldp = %d)",
                 RP_MAXM, n, ldp);
   SAM6D_REQUIRE(xmax > 0.f, "rpe_scores: xmax must be positive");
@@ -464,8 +496,10 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
   if (sam6d_first_use_on_device(&rpe_done, &dev)) {
     SAM6D_REQUIRE(dev >= 0, "rpe_scores: device ordinal beyond SAM6D_MAX_DEVICES");
     int cu = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cu <= 0) {
       sam6d_set_error("rpe_scores: cannot reserve %d bytes of LDS / query the device: %s", lds_max, hipGetErrorString(e));
@@ -486,9 +520,14 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
   if (lblocks > 4096) lblocks = 4096;
   hipLaunchKernelGGL(rpe_listed_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, list_ws, rows, qp, qk, n, ldp);
   SAM6D_LAUNCH_CHECK_CONT("rpe_scores(listed pairs)");
-  hipLaunchKernelGGL(rpe_score_kernel, dim3((unsigned)blocks), dim3(64 * waves), RP_WBYTES + waves * per_wave,
-                     (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), pos_ws, rows,
-                     reinterpret_cast<const unsigned char*>(wa_cheb), qp, qd, qk, P, n, ldp, Q, xmax, scale, mpad);
+  if (products == 3)
+    hipLaunchKernelGGL(rpe_score_kernel<3>, dim3((unsigned)blocks), dim3(64 * waves), RP_WBYTES + waves * per_wave,
+                       (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), pos_ws, rows,
+                       reinterpret_cast<const unsigned char*>(wa_cheb), qp, qd, qk, P, n, ldp, Q, xmax, xmax_a, scale, mpad);
+  else
+    hipLaunchKernelGGL(rpe_score_kernel<2>, dim3((unsigned)blocks), dim3(64 * waves), RP_WBYTES + waves * per_wave,
+                       (hipStream_t)stream, reinterpret_cast<const float4*>(idx_ws), pos_ws, rows,
+                       reinterpret_cast<const unsigned char*>(wa_cheb), qp, qd, qk, P, n, ldp, Q, xmax, xmax_a, scale, mpad);
   SAM6D_LAUNCH_CHECK("rpe_scores");
 }
 

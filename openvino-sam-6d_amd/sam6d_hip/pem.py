@@ -26,7 +26,7 @@ def _s():
 class _Flags:
     """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
     ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid")
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products")
 
     def __init__(self):
         env = os.environ.get
@@ -38,6 +38,7 @@ class _Flags:
         self.score_mfma = env("SAM6D_SCORE_MFMA", "1") == "1"  # hypothesis scoring: distance products on the fp32 matrix cores
         self.bq_grid = env("SAM6D_BQ_GRID", "1") == "1"  # ball queries through the cell grid (identical indices)
         self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
+        self.rpe_products = int(env("SAM6D_RPE_PRODUCTS", "0"))  # 0: what the weight set allows (geo_cheb_a_packed); 3: always three
 
 
 _FLAGS = None
@@ -508,6 +509,37 @@ def geo_cheb_packed(W):
     return pk
 
 
+def geo_cheb_a_packed(W, sigma_a=15):
+    """proj_a's Chebyshev image for the fused score kernel (rpe.hip), on the range the angular indices actually live on: the angle of
+    get_embedding_indices (PEM/model/transformer.py:326-341) is at most pi, so a_idx = angle * 180 / (sigma_a pi) <= 180 / sigma_a
+    (12 for the reference's sigma_a = 15) against GEO_XMAX = 24 for the distance index.  On the shorter range the coefficients fall
+    off twice as fast (|c_p| ~ J_p(xmax_a / 2)), which is what lets the kernel drop the cross terms of the orders >= 16.
+    Returns (image (256, 72) fp16 = [32 hi | 32 lo | pad] of c * 1024, xmax_a, products, fits):
+      products = 2 when, for every channel, 2^-10 sum_{p >= 16} |c[ch][p]| <= 3e-8 of that channel's bound sum_p |c[ch][p]| (never
+                 below 1e-3 of the largest channel's) -- half an fp32 ulp of the values the reference computes -- else 3;
+      fits     = sum_p |1024 c[ch][p]| < 60 000 (the kernel's fp16 split of the projected embedding cannot overflow)."""
+    cache = getattr(W, "_geo_cheb_a", None)
+    if cache is None:
+        cache = W._geo_cheb_a = {}
+    key = float(sigma_a)
+    hit = cache.get(key)
+    if hit is None:
+        import numpy as np
+        xmax_a = min(float(GEO_XMAX), (180.0 / float(sigma_a)) * (1.0 + 2.0 ** -6))
+        c = cheb_coefficients(W.geo_a.w, W.div_term, xmax=xmax_a)  # (256, 32) float64
+        bound = np.abs(c).sum(axis=1)
+        tail = np.abs(c[:, 16:]).sum(axis=1) * 2.0 ** -10
+        floor = max(float(bound.max()) * 1e-3, 1e-30)
+        products = 2 if bool(np.all(tail <= 3e-8 * np.maximum(bound, floor))) else 3
+        fits = bool(geo_images_in_range(W) and (bound * 1024.0).max() < 60000.0)
+        c32 = np.clip(c * 1024.0, -65000.0, 65000.0).astype(np.float32)
+        hi = c32.astype(np.float16)
+        lo = (c32 - hi.astype(np.float32)).astype(np.float16)
+        img = np.concatenate([hi, lo, np.zeros((C, 8), np.float16)], axis=1)  # (256, 72 halves = 144 B)
+        hit = cache[key] = (torch.from_numpy(np.ascontiguousarray(img)).to(W.geo_d.w.device), xmax_a, products, fits)
+    return hit
+
+
 def geo_images_in_range(W):
     """True when proj_d / proj_a x 1024 and their Chebyshev coefficients x 1024 are all finite in fp16, i.e. the split-precision
     embedding kernels (sam6d_geo_embed_cheb / _h3 and the outlier rows) can serve this weight set; otherwise geo_embedding uses the
@@ -516,10 +548,9 @@ def geo_images_in_range(W):
     return W._geo_img_fits
 
 
-def fused_rpe_in_range(W):
+def fused_rpe_in_range(W, sigma_a=15):
     """True when the fused RPE score kernel's fp16 split of the projected embedding cannot overflow for this weight set."""
-    geo_cheb_packed(W)
-    return W._geo_cheb_fits
+    return geo_cheb_a_packed(W, sigma_a)[3]
 
 
 def geo_packed(W):
@@ -541,7 +572,7 @@ def geo_packed(W):
 class GeoContext:
     """What the fused RPE attention needs instead of the (B,n,n,256) embedding tensor: the per-pair embedding indices, the
     map pair -> stored row for the pairs outside the Chebyshev range, those rows, and the packed coefficient matrices."""
-    __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "dcT", "dcT16", "keep")
+    __slots__ = ("B", "n", "idx", "pos", "rows", "wa_cheb", "xmax_a", "products", "dcT", "dcT16", "keep")
 
 
 def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
@@ -549,7 +580,8 @@ def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     PEM/model/transformer.py:306-363; the projections are applied inside sam6d_rpe_scores)."""
     B, n, _ = points_bg.shape
     pairs = B * n * n
-    if not fused_rpe_in_range(W):
+    img, xmax_a, products, fits = geo_cheb_a_packed(W, sigma_a)
+    if not fits:
         raise ValueError("geo_context: proj_a of this weight set exceeds the fp16 range of the fused RPE score kernel "
                          "(sum |Chebyshev coefficients| >= 58.6 per channel); use geo_embedding (SAM6D_FUSED_RPE=0)")
     knn = _empty((B * n * angle_k + 1,), points_bg, torch.int32)  # + the range flag
@@ -562,10 +594,11 @@ def geo_context(points_bg, W, sigma_d=0.2, sigma_a=15, angle_k=3):
     G.pos = _empty((pairs,), points_bg, torch.int32)
     lst = _empty((pairs + 1,), points_bg, torch.int32)
     G.rows = _empty((pairs, C), points_bg)  # capacity for the worst case; only the listed rows are ever touched
-    _lib.call("sam6d_geo_outliers", _p(idx), pairs, float(GEO_XMAX), _p(W.div_term), geo_packed(W).data_ptr(), _p(W.geo_d.w),
-              _p(W.geo_a.w), flag, _p(G.pos), _p(lst), _p(G.rows), _s())
-    img = geo_cheb_packed(W)
-    G.wa_cheb = img.data_ptr() + C * 144  # the proj_a half of the [mat][col][144 B] image
+    _lib.call("sam6d_geo_outliers2", _p(idx), pairs, float(GEO_XMAX), float(xmax_a), _p(W.div_term), geo_packed(W).data_ptr(),
+              _p(W.geo_d.w), _p(W.geo_a.w), flag, _p(G.pos), _p(lst), _p(G.rows), _s())
+    G.wa_cheb = img.data_ptr()  # proj_a's expansion on [0, xmax_a]
+    G.xmax_a = xmax_a
+    G.products = 3 if _flags().rpe_products == 3 else products
     G.dcT = geo_dcT(W)
     G.dcT16 = geo_dcT16(W)
     G.keep = (knn, lst, img)
@@ -646,8 +679,8 @@ def _rpe_self_tail(x, x2, G, L, qkv, qp, qd, vT=None):
     P = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
     with _Timed("rpe_score_kernel"):
-        _lib.call("sam6d_rpe_scores", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX), _p(qp), _p(qd),
-                  _p(qk), _p(P), M, n, ldp, _s())
+        _lib.call("sam6d_rpe_scores2", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX), float(G.xmax_a),
+                  int(G.products), _p(qp), _p(qd), _p(qk), _p(P), M, n, ldp, _s())
     if vT is None:
         vT = _empty((Bp, C, ldp), x)
         _lib.call("sam6d_transpose", _p(qkv, 2 * C), 3 * C, n * 3 * C, Bp, n, C, _p(vT), ldp, C * ldp, _s())

@@ -33,17 +33,18 @@ pem.gemm(qp, G.dcT, None, qd, M * H, 32, C, C, C, 32)
 qk = pem._empty((M, H, ldp), x)
 pem.gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)
 P = pem._empty((M, H, ldp), x)
-def run():
-    _lib.call("sam6d_rpe_scores", pem._p(G.idx), pem._p(G.pos), pem._p(G.keep[1]), pem._p(G.rows), G.wa_cheb, float(pem.GEO_XMAX),
-              pem._p(qp), pem._p(qd), pem._p(qk), pem._p(P), M, n, ldp, pem._s())
-for _ in range(3): run()
-torch.cuda.synchronize()
+def run(products):
+    _lib.call("sam6d_rpe_scores2", pem._p(G.idx), pem._p(G.pos), pem._p(G.keep[1]), pem._p(G.rows), G.wa_cheb, float(pem.GEO_XMAX),
+              float(G.xmax_a), products, pem._p(qp), pem._p(qd), pem._p(qk), pem._p(P), M, n, ldp, pem._s())
 a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(10): run()
-b.record(); torch.cuda.synchronize()
-ms = a.elapsed_time(b) / 10
-print("rpe_scores: %.1f us per launch  (%.2f us per query per CU, MFMA-only bound 3.4 us)" % (ms * 1e3, ms * 1e3 * 256 / M))
+for products in (3, 2, 3, 2):
+    for _ in range(3): run(products)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10): run(products)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 10
+    print("rpe_scores, %d products: %.1f us per launch (incl. the listed-pair kernel)" % (products, ms * 1e3))
 a.record()
 for _ in range(10): pem.rpe_self_layer(x, G, L)
 b.record(); torch.cuda.synchronize()

@@ -676,6 +676,43 @@ def test_rpe_fused_query_magnitudes(dev, W, xs):
     assert torch.isfinite(got).all() and rel < 2e-5
 
 
+@pytest.mark.parametrize("sigma_a,forced", [(15, 0), (15, 3), (7.5, 0)])
+def test_rpe_stage1_two_and_three_products(dev, W, sigma_a, forced):
+    """The score kernel's stage 1 runs two MFMAs per (block, angular row) when the angular indices' own Chebyshev range ([0, 180 /
+    sigma_a]: 12 for the reference's 15 degrees) makes the cross terms of the orders >= 16 negligible (host check of
+    geo_cheb_a_packed), else three.  Both variants, and the forced three-product one on the short range, reproduce the materialised
+    layer; sigma_a = 7.5 doubles the index range (24 = the distance range), for which the check must refuse the two-product form."""
+    import os
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the fused RPE path is the default (fp16x3) mode")
+    gen = torch.Generator().manual_seed(91)
+    B, n = 3, 197
+    pts = (torch.rand(B, n, 3, generator=gen) - 0.5) * 1.6
+    pts[:, 0] = 100.0
+    x = torch.randn(B, n, 256, generator=gen)
+    L = W.coarse["blocks"][2]["self"]
+    E = pem.geo_embedding(pts.to(dev), W, sigma_a=sigma_a)
+    want = pem.rpe_self_layer(x.to(dev), E, L).cpu()
+    old = os.environ.get("SAM6D_RPE_PRODUCTS")
+    try:
+        if forced:
+            os.environ["SAM6D_RPE_PRODUCTS"] = str(forced)
+        G = pem.geo_context(pts.to(dev), W, sigma_a=sigma_a)
+        got = pem.rpe_self_layer(x.to(dev), G, L).cpu()
+    finally:
+        if old is None:
+            os.environ.pop("SAM6D_RPE_PRODUCTS", None)
+        else:
+            os.environ["SAM6D_RPE_PRODUCTS"] = old
+    assert G.products == (3 if (forced == 3 or sigma_a != 15) else 2), (G.products, G.xmax_a)
+    assert abs(G.xmax_a - min(24.0, 180.0 / sigma_a * (1 + 2.0 ** -6))) < 1e-6
+    d = float((got - want).abs().max())
+    print("\nfused RPE layer, sigma_a %g, products %d, xmax_a %.4f: max abs diff %.2e (scale %.1f)"
+          % (sigma_a, G.products, G.xmax_a, d, float(want.abs().max())))
+    assert torch.isfinite(got).all() and d < 2e-5
+
+
 def test_rpe_fused_range_guard(dev, sd):
     """Weights whose projected angular embedding could leave the fp16 range of the score kernel's second contraction are detected on
     the host (sum of |Chebyshev coefficients| per channel) and keep the materialised-embedding path; weights whose x1024 images would
