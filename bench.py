@@ -330,15 +330,25 @@ def main():
             achieved = flop / (k_ms * 1e-3) / 1e12 if ev else None
             peak = PEAK_FP16_MFMA_TFLOPS / (1.0 if mode == 2 else 3.0)
             ref_flop = clouds * (PROJP_FLOP_PER_CLOUD + GEO_FLOP_PER_CLOUD / 6.0)
+            # MFMA products the kernel executes per fp32 product: stage 1 (3 x 256 x 32 per pair) 3, or 2 where the host check of
+            # pem.geo_cheb_a_packed lets the cross terms of the orders >= 16 go; stage 2 (4 x 256 per pair) always 3.  `peak` stays the
+            # three-product bound of rounds 1-2 (the yardstick of `frac`); the bound of the formulation as executed is reported beside it.
+            np1 = 1 if mode == 2 else (3 if os.environ.get("SAM6D_RPE_PRODUCTS", "0") == "3" else pem.geo_cheb_a_packed(W)[2])
+            np2 = 1 if mode == 2 else 3
+            f1, f2 = 3 * 256 * 32, 4 * 256
+            exec_ratio = (np1 * f1 + np2 * f2) / float(f1 + f2 + 4 * 32)  # executed fp16 MFMA flops per algorithmic flop (d part: vector)
             roofline = {"bound": "mfma",
-                        "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16x3 split = 3 MFMA products per fp32 product), "
-                                  "with its outlier-pair kernel; one RPE layer over %d clouds per launch, %d launches per step%s"
-                                  % (clouds, 6 * mb, "" if mb == 1 else " on %d concurrent streams (durations include the other "
+                        "kernel": "rpe_score_kernel (v_mfma_f32_16x16x32_f16, fp16 split precision: %d MFMA products per fp32 product in "
+                                  "stage 1, %d in stage 2), with its outlier-pair kernel; one RPE layer over %d clouds per launch, %d "
+                                  "launches per step%s"
+                                  % (np1, np2, clouds, 6 * mb, "" if mb == 1 else " on %d concurrent streams (durations include the other "
                                      "streams' kernels)" % mb),
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                         "traffic": traffic, "launch_ms": k_ms, "launches_timed": len(ms),
                         "algorithmic_gflop_per_launch": flop / 1e9,
-                        "executed_mfma_tflops": ((1.0 if mode == 2 else 3.0) * achieved * (208.0 / 197.0)) if achieved else None,
+                        "executed_mfma_tflops": (exec_ratio * achieved * (208.0 / 197.0)) if achieved else None,
+                        "stage1_products": np1, "peak_as_executed": PEAK_FP16_MFMA_TFLOPS / exec_ratio,
+                        "frac_as_executed": (achieved * exec_ratio / PEAK_FP16_MFMA_TFLOPS) if achieved else None,
                         "reference_formulation_gflop_per_launch": ref_flop / 1e9,
                         "reference_formulation_tflops": (ref_flop / (k_ms * 1e-3) / 1e12) if ev else None,
                         "fp16_mfma_peak": PEAK_FP16_MFMA_TFLOPS}

@@ -325,7 +325,9 @@ template <int KS, int S, int FD_>
 __device__ __forceinline__ void tb_mma_step(f32x4& acc0, f32x4& acc1, const unsigned (&a)[4], const half8* __restrict__ xh,
                                             const half8* __restrict__ xl, tb_u32x4 (&f)[FD_ + 1][4], bool half) {
   constexpr int cur = S % (FD_ + 1);
+#ifndef TB_ABL_NOREAD  // (scratch/abl_build.sh: timing-only builds without the fragment reads / the panel DMA / the panel barrier)
   if constexpr (S + FD_ < KS) tb_load_step<KS, S + FD_>(a, f[(S + FD_) % (FD_ + 1)]);
+#endif
   constexpr int newer = (KS - 1 - S) < FD_ ? (KS - 1 - S) : FD_;  // steps requested after this one
   tb_wait<4 * newer>(f[cur][0], f[cur][1], f[cur][2], f[cur][3]);
   const half8 h0 = __builtin_bit_cast(half8, f[cur][0]), l0 = __builtin_bit_cast(half8, f[cur][1]);
@@ -555,9 +557,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
     TB_ST(4 + 3 * I);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     TB_ST(5 + 3 * I);
+#ifndef TB_ABL_NOBAR
     __syncthreads();
+#endif
     TB_ST(6 + 3 * I);
+#ifndef TB_ABL_NODMA
     dma(std::integral_constant<int, I + NBUF - 1>{});
+#endif
     return pan_lds + (I % TB_NBUF) * TB_PANEL_BYTES;
   };
 

@@ -5,7 +5,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "openvino-sam-6d_amd"))
 import torch
-from sam6d_hip import pem, synth, _lib
+from sam6d_hip import _lib
+if os.environ.get("LIBP"): _lib.LIB_PATH = os.environ["LIBP"]
+from sam6d_hip import pem, synth
 dev = torch.device("cuda:0")
 W = pem.PemWeights(synth.make_pem_weights(1), dev)
 B = 32
@@ -86,8 +88,11 @@ ops = {
     "self_layer": lambda: pem.rpe_self_layer(S, G, T["self"]),
     "cross_layer": lambda: pem.cross_layer(S[:B], S[B:], T["cross"]),
     "geo_transformer_block": lambda: pem.geometric_transformer(S, G, T),
+    "dense_layer": lambda: pem.linear_transformer_layer(DD, S, FT),
     "kv_linear_6304": lambda: pem.linear(x2[:6304], T["cross"]["kv"]),
 }
-want = sys.argv[1:] or list(ops)
+DD = torch.randn(2 * B, 2049, 256, generator=g).to(dev) if "dense_layer" in sys.argv else None
+FT = W.fine["blocks"][0]["dense"] if "dense" in W.fine["blocks"][0] else None
+want = sys.argv[1:] or [k for k in ops if k != "dense_layer"]
 for name in want:
     timeit(name, ops[name])

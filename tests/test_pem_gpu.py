@@ -687,7 +687,7 @@ def test_rpe_stage1_two_and_three_products(dev, W, sigma_a, forced):
     if _lib.load().sam6d_get_matmul_mode() != 1:
         pytest.skip("the fused RPE path is the default (fp16x3) mode")
     gen = torch.Generator().manual_seed(91)
-    B, n = 3, 197
+    B, n = 17, 197  # 3349 queries: every one of the 256 persistent workgroups runs more queries than it has waves
     pts = (torch.rand(B, n, 3, generator=gen) - 0.5) * 1.6
     pts[:, 0] = 100.0
     x = torch.randn(B, n, 256, generator=gen)
