@@ -464,6 +464,9 @@ struct TbSched {
     if (i < 8) return (32 + WAVES - 1) / WAVES;
     return ((((i - 8) % 12) < 4 ? 32 : 16) + WAVES - 1) / WAVES;
   }
+  static constexpr int per_issuer(int i, int nw) {  // pieces of panel i each of nw issuing waves copies
+    return (i < 0 || i >= NPAN) ? 0 : (pieces(i) + nw - 1) / nw;
+  }
   static constexpr int pieces(int i) {  // 1 KiB pieces of panel i
     if (MODE && i >= 8 && i < 16) return 8;
     const int k = MODE ? i - 16 : i;
@@ -485,17 +488,23 @@ extern "C" int sam6d_tb_debug_stamps(void* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tb_stamps), sizeof(unsigned long long) * 512 * 8 * TB_NSTAMP);
 }
 // (stamps go to LDS and are flushed at the end: a global store before a panel's s_waitcnt vmcnt would itself be waited for)
-#define TB_ST(i) do { if (lane == 0 && (i) < TB_NSTAMP) st_lds[wave][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TB_ST(i) do { if (lane == 0 && wave < WAVES && (i) < TB_NSTAMP) st_lds[wave][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TB_ST(i)
 #endif
 
-template <int MODE, int WAVES, int NBUF, int FD = TB_FD>
-__global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) {  // (2 waves per SIMD: <= 256 VGPR + AGPR)
+// LOADERS > 0: that many extra waves do nothing but the panel DMA (wait for their pieces, join the barrier, issue the next step), so
+// the ~45 issue cycles of each 1 KiB piece (8 per wave and K = 256 panel) leave the computing waves' instruction streams; PSTEP = 2:
+// a ring slot holds two consecutive panels and the barrier comes every other panel.  Both only where one workgroup per CU runs anyway
+// (the 197-token layers: 197 workgroups on 256 CUs).
+template <int MODE, int WAVES, int NBUF, int FD = TB_FD, int LOADERS = 0, int PSTEP = 1>
+__global__ __launch_bounds__((WAVES + LOADERS) * 64, 2) void token_block_kernel(TbArgs a) {  // (2 waves per SIMD: <= 256 VGPR + AGPR)
   constexpr int TB_TOK = 16 * WAVES, TB_NBUF = NBUF;
+  constexpr int NTHREADS = (WAVES + LOADERS) * 64;
+  constexpr int SLOT_BYTES = PSTEP * TB_PANEL_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* pan = lds;                                                   // TB_NBUF x TB_PANEL_BYTES ring
-  float* cst = reinterpret_cast<float*>(lds + TB_NBUF * TB_PANEL_BYTES);      // TC_N floats
+  unsigned char* pan = lds;                                                   // TB_NBUF slots of PSTEP panels
+  float* cst = reinterpret_cast<float*>(lds + TB_NBUF * SLOT_BYTES);          // TC_N floats
   float* ksm = cst + TC_N;                                                    // 256 floats (mode 1)
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   typedef TbSched<MODE, WAVES> SCH;
@@ -523,10 +532,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   }
 
   const unsigned char* kvp = MODE ? a.kvimg + (size_t)b * (8 * TB_P64) : nullptr;
-  // LDS-DMA of panel I into ring slot I % TB_NBUF: SCH::per_wave(I) pieces of 1 KiB per wave (the global image IS the LDS image)
+  static_assert(SCH::NPAN % PSTEP == 0, "whole steps");
+  constexpr int NW = LOADERS ? LOADERS : WAVES;        // waves that issue the DMA
+  const bool issuer = LOADERS ? wave >= WAVES : true;
+  const int lw = LOADERS ? wave - WAVES : wave;        // index among the issuing waves
+  // LDS-DMA of panel I into its ring slot: SCH::per_issuer(I, NW) pieces of 1 KiB per issuing wave (the global image IS the LDS image)
   auto dma = [&](auto IC) {
     constexpr int I = decltype(IC)::value;
-    constexpr int NP = SCH::per_wave(I);
+    constexpr int NP = SCH::per_issuer(I, NW);
     if constexpr (NP > 0) {
       constexpr int K = MODE ? I - 16 : I;   // index in the common part (negative: proj_q / kv panels)
       const unsigned char* src;
@@ -538,10 +551,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
         constexpr size_t base = 8 * (size_t)TB_P256 + c * (size_t)TB_CHUNK_BYTES;
         src = a.wimg + (u < 4 ? base + u * (size_t)TB_P256 : base + 4 * (size_t)TB_P256 + (u - 4) * (size_t)TB_P128);
       }
-      unsigned char* dst = pan + (I % TB_NBUF) * TB_PANEL_BYTES;
+      unsigned char* dst = pan + ((I / PSTEP) % TB_NBUF) * SLOT_BYTES + (I % PSTEP) * TB_PANEL_BYTES;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        const int pc = wave + WAVES * k;
+        const int pc = lw + NW * k;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
                                          (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
       }
@@ -550,26 +563,47 @@ __global__ __launch_bounds__(WAVES * 64, 2) void token_block_kernel(TbArgs a) { 
   // Start of panel I: this wave's pieces of panel I have landed once at most the pieces of the panels issued after it (I+1 ..
   // I+NBUF-2; the vector-memory counter retires in order) are outstanding; the barrier then publishes the panel to the other waves
   // and at the same time retires panel I-1 in every wave, whose ring slot the DMA of panel I+NBUF-1 overwrites.
-  auto next_panel = [&](auto IC) -> unsigned {
-    constexpr int I = decltype(IC)::value;
-    static_assert(NBUF == 2 || (32 % WAVES) == 0, "counted waits need the same number of pieces in every wave");
-    constexpr int N = SCH::template in_flight<NBUF>(I);
-    TB_ST(4 + 3 * I);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    TB_ST(5 + 3 * I);
+  // pieces per issuing wave of the steps T+1 .. T+NBUF-2 (in flight while step T is awaited)
+  auto step_in_flight = [](int T) constexpr {
+    int n = 0;
+    for (int k = 1; k <= NBUF - 2; ++k)
+      for (int p = 0; p < PSTEP; ++p) n += SCH::per_issuer((T + k) * PSTEP + p, NW);
+    return n;
+  };
+  auto dma_step = [&](auto TC) {  // all panels of step T
+    constexpr int T = decltype(TC)::value;
+    tb_static_for<0, PSTEP>([&](auto PC) { dma(std::integral_constant<int, T * PSTEP + decltype(PC)::value>{}); });
+  };
+  auto step_sync = [&](auto TC) {  // start of step T: its panels have landed and are published; the slot of step T-1 is free
+    constexpr int T = decltype(TC)::value;
+    static_assert(NBUF == 2 || (32 % NW) == 0, "counted waits need the same number of pieces in every wave");
+    constexpr int N = step_in_flight(T);
+    TB_ST(4 + 3 * T);
+    if (issuer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    TB_ST(5 + 3 * T);
 #ifndef TB_ABL_NOBAR
     __syncthreads();
 #endif
-    TB_ST(6 + 3 * I);
+    TB_ST(6 + 3 * T);
 #ifndef TB_ABL_NODMA
-    dma(std::integral_constant<int, I + NBUF - 1>{});
+    if (issuer) dma_step(std::integral_constant<int, T + NBUF - 1>{});
 #endif
-    return pan_lds + (I % TB_NBUF) * TB_PANEL_BYTES;
+  };
+  auto next_panel = [&](auto IC) -> unsigned {
+    constexpr int I = decltype(IC)::value;
+    if constexpr (I % PSTEP == 0) step_sync(std::integral_constant<int, I / PSTEP>{});
+    return pan_lds + ((I / PSTEP) % TB_NBUF) * SLOT_BYTES + (I % PSTEP) * TB_PANEL_BYTES;
   };
 
-  tb_static_for<0, NBUF - 1>([&](auto IC) { dma(IC); });
-  for (int i = t; i < TC_N; i += WAVES * 64) cst[i] = a.consts[i];
+  if (issuer) tb_static_for<0, NBUF - 1>([&](auto TC) { dma_step(TC); });
+  for (int i = t; i < TC_N; i += NTHREADS) cst[i] = a.consts[i];
   if (MODE && t < 256) ksm[t] = a.ksum[(size_t)b * 256 + t];
+  if constexpr (LOADERS > 0) {
+    if (wave >= WAVES) {  // a loader wave: the barrier sequence of the computing waves, nothing else
+      tb_static_for<0, SCH::NPAN / PSTEP>([&](auto TC) { step_sync(TC); });
+      return;
+    }
+  }
 
   // ---- X: the input rows, split (mode 0: hidden; mode 1: D)
   half8 xh[8], xl[8];
@@ -835,8 +869,10 @@ struct RfArgs {
 // Stores are issued for every lane -- rows past M are clamped to row M - 1 and rewrite its values -- so that the number of vector-memory
 // operations between two panel DMAs is a compile-time constant: the wait at the head of a panel then lets the previous panel's STORES
 // stay in flight (s_waitcnt vmcnt(#stores)) instead of draining them (vmcnt(0) cost a store round trip per panel: 36 per workgroup).
-template <bool VT>
-__global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
+// LOADERS (0 / 4) extra waves issue the panel DMA, as in token_block_kernel; the computing waves then never wait on the vector-memory
+// counter at all (their stores stay in flight across panels without the counted waits below).
+template <bool VT, int LOADERS = 0>
+__global__ __launch_bounds__((4 + LOADERS) * 64, LOADERS ? 1 : 2) void rpe_front_kernel(RfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* pan = lds;  // 2 x TB_PANEL_BYTES
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
@@ -858,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
       unsigned char* dst = pan + (I & 1) * TB_PANEL_BYTES;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        const int pc = wave + 4 * k;
+        const int pc = (LOADERS ? wave - 4 : wave) + 4 * k;
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
                                          (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
       }
@@ -868,12 +904,25 @@ __global__ __launch_bounds__(256, 2) void rpe_front_kernel(RfArgs a) {
   auto next_panel = [&](auto IC, auto NSTC) -> unsigned {
     constexpr int I = decltype(IC)::value;
     constexpr int NST = decltype(NSTC)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    if constexpr (LOADERS == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     __syncthreads();
-    dma(std::integral_constant<int, I + 1>{});
+    if constexpr (LOADERS == 0) dma(std::integral_constant<int, I + 1>{});
     return pan_lds + (I & 1) * TB_PANEL_BYTES;
   };
-  dma(std::integral_constant<int, 0>{});
+  if constexpr (LOADERS > 0) {
+    static_assert(LOADERS == 4, "the DMA pieces are dealt to four waves");
+    if (wave >= 4) {  // a loader wave: unit I + 1 goes out once unit I has landed and every wave has left unit I - 1
+      dma(std::integral_constant<int, 0>{});
+      tb_static_for<0, NPAN>([&](auto IC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma(std::integral_constant<int, decltype(IC)::value + 1>{});
+      });
+      return;
+    }
+  } else {
+    dma(std::integral_constant<int, 0>{});
+  }
 
   half8 xh[8], xl[8];
   float sx;
@@ -1004,6 +1053,8 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
   if (sam6d_first_use_on_device(&done)) {
     hipError_t e = hipFuncSetAttribute((const void*)rpe_front_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rpe_front_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rpe_front_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rpe_front_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
     if (e != hipSuccess) {
       sam6d_set_error("rpe_front: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -1011,23 +1062,37 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
     sam6d_setup_done_on_device(&done);
   }
   RfArgs a{x, (const unsigned char*)wimage, bias_qkv, qkv, qp, qd, M, inv_qkv, inv_wp, inv_dc, vT, n, ldp};
-  if (vT)
-    hipLaunchKernelGGL(rpe_front_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  static int loaders = -1;  // four loader waves beside the four computing ones (SAM6D_FRONT_LOADERS=0: the plain shape, for A/B runs)
+  if (loaders < 0) {
+    const char* e = getenv("SAM6D_FRONT_LOADERS");
+    loaders = (e && e[0] == '0') ? 0 : 4;
+  }
+  const dim3 g((unsigned)((M + 63) / 64));
+  if (vT && loaders)
+    hipLaunchKernelGGL((rpe_front_kernel<true, 4>), g, dim3(512), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  else if (vT)
+    hipLaunchKernelGGL((rpe_front_kernel<true, 0>), g, dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  else if (loaders)
+    hipLaunchKernelGGL((rpe_front_kernel<false, 4>), g, dim3(512), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(rpe_front_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((rpe_front_kernel<false, 0>), g, dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("rpe_front");
 }
 
 #define TB_LDS_BYTES(NBUF) ((NBUF) * TB_PANEL_BYTES + (TC_N + 256) * 4)
+#define TB_LDS_BYTES2(NBUF, PSTEP) ((NBUF) * (PSTEP) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 
 // Two shapes of the same kernel: 4 waves x 16 tokens with a 2-slot panel ring (77 KB of LDS: two workgroups per CU, which run out
 // of step, so one's row epilogues overlap the other's MFMAs), and 8 waves x 16 tokens with a 4-slot ring (one workgroup per CU).
 // SAM6D_BLOCK_SHAPE=8 selects the latter (kept for A/B measurements).
+// The 197-token layers (sam6d_token_block) default to 4 computing + 4 loader waves with two panels per ring slot (shape 142); "4" is the
+// plain 4-wave shape there, "4L" / "4P" loader waves / two-panel steps alone.
 static int tb_shape() {
   static int shape = 0;
   if (!shape) {
     const char* e = getenv("SAM6D_BLOCK_SHAPE");
-    shape = (e && e[0] == '8') ? 8 : (e && e[0] == '4' && e[1] == '4') ? 44 : 4;
+    shape = !e ? 142 : e[0] == '8' ? 8 : (e[0] == '4' && e[1] == '4') ? 44 : (e[0] == '4' && e[1] == 'L') ? 141 :
+            (e[0] == '4' && e[1] == 'P') ? 42 : e[0] == '4' ? 4 : 142;
   }
   return shape;
 }
@@ -1050,6 +1115,9 @@ static int tb_set_attr() {
     if (!rc) rc = tb_attr(token_block_kernel<0, 8, 4>, TB_LDS_BYTES(4));
     if (!rc) rc = tb_attr(token_block_kernel<0, 4, 4>, TB_LDS_BYTES(4));
     if (!rc) rc = tb_attr(token_block_kernel<1, 8, 4>, TB_LDS_BYTES(4));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 4, 2>, TB_LDS_BYTES2(2, 2));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 4, 1>, TB_LDS_BYTES2(2, 1));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 0, 2>, TB_LDS_BYTES2(2, 2));
     if (rc) return rc;
     sam6d_setup_done_on_device(&done0);
   }
@@ -1065,7 +1133,14 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   if (rc) return rc;
   TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps,
            sam6d_half_for(1)};
-  if (tb_shape() == 44)
+  const dim3 g64((unsigned)((M + 63) / 64));
+  if (tb_shape() == 142)
+    hipLaunchKernelGGL((token_block_kernel<0, 4, 2, TB_FD, 4, 2>), g64, dim3(512), TB_LDS_BYTES2(2, 2), (hipStream_t)stream, a);
+  else if (tb_shape() == 141)
+    hipLaunchKernelGGL((token_block_kernel<0, 4, 2, TB_FD, 4, 1>), g64, dim3(512), TB_LDS_BYTES2(2, 1), (hipStream_t)stream, a);
+  else if (tb_shape() == 42)
+    hipLaunchKernelGGL((token_block_kernel<0, 4, 2, TB_FD, 0, 2>), g64, dim3(256), TB_LDS_BYTES2(2, 2), (hipStream_t)stream, a);
+  else if (tb_shape() == 44)
     hipLaunchKernelGGL((token_block_kernel<0, 4, 4>), dim3((unsigned)((M + 63) / 64)), dim3(256), TB_LDS_BYTES(4), (hipStream_t)stream, a);
   else if (tb_shape() == 8)
     hipLaunchKernelGGL((token_block_kernel<0, 8, 4>), dim3((unsigned)((M + 127) / 128)), dim3(512), TB_LDS_BYTES(4), (hipStream_t)stream, a);
