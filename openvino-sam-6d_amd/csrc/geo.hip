@@ -119,13 +119,15 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
                                                            const int* __restrict__ list, int compact) {
   if (only_if_large && *maxflag == 0) return;  // fallback launch behind the fp16x3 kernel: nothing to do
   if (list) total = list[0];                   // list mode: see geo_embed_h3_kernel
-  if ((long)blockIdx.x * GE_P >= total) return;
+  // blocks of GE_P pairs, grid-strided: the list-mode launches size their grid for a few thousand listed pairs, not for the worst
+  // case (every pair listed), whose ~10^5 workgroups did nothing but exit
+  for (long blk = blockIdx.x; blk * GE_P < total; blk += gridDim.x) {
   __shared__ float As[4 * GE_P * GE_LD];       // 128 rows
   __shared__ float Bs[2 * 256 * GE_LD];        // [mat][col][k]
   __shared__ float xs[4 * GE_P];               // embedding index of each generated row
   __shared__ int pid[GE_P];                    // output row of each slot
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const long p0 = (long)blockIdx.x * GE_P;
+  const long p0 = blk * GE_P;
   if (t < GE_P) {
     const long slot = min(p0 + t, total - 1);
     const long e = list ? (long)list[1 + slot] : slot;
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void geo_embed_kernel(const float4* __restr
       }
     }
   }
+  __syncthreads();  // the next block of pairs reuses the LDS tiles
+  }
 }
 
 
@@ -236,15 +240,15 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
   if (*maxflag != 0) return;  // an index beyond the fast sincos range: the exact kernel launched next handles the call
   // list mode (fix-up pass behind geo_cheb_kernel): list[0] = number of listed pairs, list[1..] = their flat pair ids
   if (list) total = list[0];
-  if ((long)blockIdx.x * GH_P >= total) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  for (long blk = blockIdx.x; blk * GH_P < total; blk += gridDim.x) {  // grid-strided blocks of GH_P pairs (see geo_embed_kernel)
   _Float16* Ah = reinterpret_cast<_Float16*>(lds_raw);  // [256][24]
   _Float16* Al = Ah + 4 * GH_P * GH_LD;
   unsigned char* Bb = lds_raw + GH_ABYTES;               // 2 x [512 rows][80 B], filled by LDS-DMA
   float* xs = reinterpret_cast<float*>(Bb + 2 * GH_BCHUNK);  // [4][64]
   float* om = xs + 4 * GH_P;                                 // [128] frequencies (bit-identical copy of div_term)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const long p0 = (long)blockIdx.x * GH_P;
+  const long p0 = blk * GH_P;
   // weights: the global image of a chunk IS the LDS image (rows of 80 B), so each wave copies 5 x 1 KiB pieces with
   // global_load_lds_dwordx4 (no VGPRs, no ds_write); double-buffered, chunk kc+1 streams in under chunk kc's MFMAs
   auto dma = [&](int kc) {
@@ -339,6 +343,8 @@ __global__ __launch_bounds__(512) void geo_embed_h3_kernel(const float4* __restr
         out[e * 256 + col] = d + a;
       }
     }
+  }
+  __syncthreads();  // the next block of pairs reuses the LDS images
   }
 }
 
@@ -616,9 +622,9 @@ extern "C" int sam6d_geo_embed_cheb(const float* idx_ws, long pairs, const void*
                      reinterpret_cast<const float4*>(idx_ws), reinterpret_cast<const unsigned char*>(w_cheb), bd, ba, out, pairs,
                      xmax, flag, (const int*)pos_ws);
   SAM6D_LAUNCH_CHECK_CONT("geo_embed_cheb");
-  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)ntiles), dim3(512), GH_LDS_BYTES, s,
+  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(512), GH_LDS_BYTES, s,
                      reinterpret_cast<const float4*>(idx_ws), div_term, reinterpret_cast<const unsigned char*>(w_packed), bd, ba,
-                     out, pairs, flag, (const int*)list_ws, 0);
+                     out, pairs, flag, (const int*)list_ws, 0);  // list mode: grid-strided over the listed pairs
   SAM6D_LAUNCH_CHECK("geo_embed_cheb(fix-up)");
 }
 
@@ -647,11 +653,13 @@ extern "C" int sam6d_geo_outliers2(const float* idx_ws, long pairs, float xmax, 
   SAM6D_LAUNCH_CHECK_CONT("geo_outliers(classify)");
   // rows of the listed pairs, bias-free, compact.  The grid covers the worst case (every pair listed); workgroups beyond
   // the device-side count return at once.  Default: fp16x3 sinusoid kernel; *flag != 0: the exact sincosf kernel.
-  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)((pairs + GH_P - 1) / GH_P)), dim3(512), GH_LDS_BYTES, s,
+  const long cap = 2048;  // list mode: the kernels stride over the listed pairs (the count lives on the device)
+  const long g_h3 = (pairs + GH_P - 1) / GH_P, g_ex = (pairs + GE_P - 1) / GE_P;
+  hipLaunchKernelGGL(geo_embed_h3_kernel, dim3((unsigned)(g_h3 < cap ? g_h3 : cap)), dim3(512), GH_LDS_BYTES, s,
                      reinterpret_cast<const float4*>(idx_ws), div_term, reinterpret_cast<const unsigned char*>(w_packed),
                      (const float*)nullptr, (const float*)nullptr, rows, pairs, flag, (const int*)list_ws, 1);
   SAM6D_LAUNCH_CHECK_CONT("geo_outliers(h3 rows)");
-  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, s,
+  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)(g_ex < cap ? g_ex : cap)), dim3(256), 0, s,
                      reinterpret_cast<const float4*>(idx_ws), div_term, Wd, (const float*)nullptr, Wa, (const float*)nullptr, rows,
                      pairs, flag, 1, (const int*)list_ws, 1);
   SAM6D_LAUNCH_CHECK("geo_outliers(exact rows)");
@@ -686,7 +694,9 @@ extern "C" int sam6d_geo_embed(const float* idx_ws, long pairs, const float* div
   SAM6D_REQUIRE(hidden == 256 && pairs >= 0, "geo_embed: hidden_dim must be 256");
   SAM6D_REQUIRE((((size_t)idx_ws | (size_t)Wd | (size_t)Wa) & 15) == 0, "geo_embed: idx_ws/weights must be 16-byte aligned");
   if (pairs == 0) return 0;
-  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)((pairs + GE_P - 1) / GE_P)), dim3(256), 0, (hipStream_t)stream,
+  // the fallback launch behind the fp16x3 kernel normally has nothing to do: a bounded grid (the kernel strides over the pairs when it has)
+  const long g_all = (pairs + GE_P - 1) / GE_P, g_use = (only_if_large && g_all > 4096) ? 4096 : g_all;
+  hipLaunchKernelGGL(geo_embed_kernel, dim3((unsigned)g_use), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(idx_ws), div_term, Wd, bd, Wa, ba, out, pairs, flag, only_if_large,
                      (const int*)nullptr, 0);
   SAM6D_LAUNCH_CHECK("geo_embed");
