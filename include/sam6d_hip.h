@@ -225,6 +225,14 @@ int sam6d_geo_outliers2(const float* idx_ws, long pairs, float xmax, float xmax_
 int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb, float xmax,
                       float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q, int n, int ldp,
                       void* stream);
+/* The same layer with the attention itself in one launch per (cloud, head) (RPEMultiHeadAttention.forward,
+ * PEM/model/transformer.py:405-416): sam6d_rpe_geo_scores writes only the geometric score term G[q][h][0..n) = qp[q][h] . E[q][m]
+ * (row stride ldp, not yet divided by 8; arguments as sam6d_rpe_scores2 without qk); sam6d_rpe_self_attention then computes, for
+ * qkv (B n, 768) = q | k | v of sam6d_rpe_front, hidden[:, 64h .. 64h+64) = softmax((q_h k_h^T + G) / 8) v_h  (n <= 208, ldp a
+ * multiple of 4).  Replaces the q.k^T GEMM, the softmax inside sam6d_rpe_scores2 and the P.v GEMM. */
+int sam6d_rpe_geo_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb, float xmax,
+                         float xmax_a, int products, const float* qp, const float* qd, float* G, long Q, int n, int ldp, void* stream);
+int sam6d_rpe_self_attention(const float* qkv, const float* G, float* hidden, int B, int n, int ldp, void* stream);
 int sam6d_transpose(const float* src, long ld_src, long stride_src, int B, int n, int ncol, float* dst, long ld_dst,
                     long stride_dst, void* stream);
 

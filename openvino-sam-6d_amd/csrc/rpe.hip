@@ -121,7 +121,9 @@ extern "C" int sam6d_rpe_debug_phases(void* dst) {
 // read with another per-lane address, the basis fragment one v_permlane32_swap per register) -- the cross terms of the orders >= 16
 // are dropped, which the host allows when 2^-10 sum_{p >= 16} |c[ch][p]| is below 3e-8 of the channel's bound (pem.py
 // geo_cheb_a_packed: the angular indices live on [0, 12.125], where the coefficients of order 16 are ~1e-6 of the leading ones).
-template <int NP>
+// RAW: P receives the geometric score term itself (4 x n floats per query, listed keys 0, not yet scaled by 1/8) instead of the softmax
+// probabilities; q.k^T, the softmax and P.v then happen in sattn_kernel (xattn.hip), and Se is not read.
+template <int NP, bool RAW = false>
 __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict__ idx4, const int* __restrict__ pos,
                                                          const float* __restrict__ rows, const unsigned char* __restrict__ Wc,
                                                          const float* __restrict__ qp, const float* __restrict__ qd,
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
 #pragma unroll
     for (int h = 0; h < 4; ++h)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sev[h][u] = lane + 64 * u < n ? Se[(q * 4 + h) * ldp + lane + 64 * u] : 0.f;
+      for (int u = 0; u < 4; ++u) sev[h][u] = (!RAW && lane + 64 * u < n) ? Se[(q * 4 + h) * ldp + lane + 64 * u] : 0.f;
     const long pbase = q * n;
     float4 v = idx4[pbase + min(kx, n - 1)];
     int ps = pos[pbase + min(kx, n - 1)];
@@ -402,6 +404,17 @@ __global__ __launch_bounds__(768) void rpe_score_kernel(const float4* __restrict
     // ---- softmax over the keys (F.softmax: exp(x - max) / sum) of (q.k + geometric term) / 8, probabilities to P[q][h][:]
     jq = take();
     if (jq < my_queries) request(blockIdx.x + (long)jq * gridDim.x);
+    if constexpr (RAW) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        float* pr = P + (q * 4 + h) * ldp;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = lane + 64 * u;
+          if (j < n) pr[j] = scw[h * mpad + j];
+        }
+      }
+    } else
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       float xv[4];
@@ -479,10 +492,27 @@ extern "C" int sam6d_rpe_scores(const float* idx_ws, const int* pos_ws, const in
   return sam6d_rpe_scores2(idx_ws, pos_ws, list_ws, rows, wa_cheb, xmax, xmax, 3, qp, qd, qk, P, Q, n, ldp, stream);
 }
 
+static int rpe_scores_impl(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
+                           float xmax, float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q, int n,
+                           int ldp, bool raw, void* stream);
 extern "C" int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
                                  float xmax, float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q,
                                  int n, int ldp, void* stream) {
-  SAM6D_REQUIRE(idx_ws && pos_ws && list_ws && rows && wa_cheb && qp && qd && qk && P, "rpe_scores: null pointer");
+  SAM6D_REQUIRE(qk, "rpe_scores: null pointer");
+  return rpe_scores_impl(idx_ws, pos_ws, list_ws, rows, wa_cheb, xmax, xmax_a, products, qp, qd, qk, P, Q, n, ldp, false, stream);
+}
+extern "C" int sam6d_rpe_geo_scores(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
+                                    float xmax, float xmax_a, int products, const float* qp, const float* qd, float* G, long Q, int n,
+                                    int ldp, void* stream) {
+  return rpe_scores_impl(idx_ws, pos_ws, list_ws, rows, wa_cheb, xmax, xmax_a, products, qp, qd, nullptr, G, Q, n, ldp, true, stream);
+}
+
+// raw = false: qk holds q.k^T, the listed pairs' terms are added to it first, P = softmax probabilities.
+// raw = true:  P = the geometric score term alone (the listed pairs' terms are added to it AFTER the score kernel has written its zeros)
+static int rpe_scores_impl(const float* idx_ws, const int* pos_ws, const int* list_ws, const float* rows, const void* wa_cheb,
+                           float xmax, float xmax_a, int products, const float* qp, const float* qd, float* qk, float* P, long Q, int n,
+                           int ldp, bool raw, void* stream) {
+  SAM6D_REQUIRE(idx_ws && pos_ws && list_ws && rows && wa_cheb && qp && qd && P, "rpe_scores: null pointer");
   SAM6D_REQUIRE(products == 2 || products == 3, "rpe_scores: products must be 2 or 3 (got %d)", products);
   SAM6D_REQUIRE(xmax_a > 0.f, "rpe_scores: xmax_a must be positive");
   SAM6D_REQUIRE(Q >= 0 && n > 0 && n <= RP_MAXM && ldp >= n, "rpe_scores: need 0 < n <= %d and ldp >= n (n = %d, ldp = %d)",
@@ -502,6 +532,10 @@ extern "C" int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rpe_score_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || cu <= 0) {
       sam6d_set_error("rpe_scores: cannot reserve %d bytes of LDS / query the device: %s", lds_max, hipGetErrorString(e));
@@ -520,6 +554,21 @@ extern "C" int sam6d_rpe_scores2(const float* idx_ws, const int* pos_ws, const i
   if (blocks > n_cu) blocks = n_cu;
   long lblocks = (Q * 2 + 3) / 4;  // about two listed pairs per query token (its bg key and its share of the bg query)
   if (lblocks > 4096) lblocks = 4096;
+  const dim3 sgrid((unsigned)blocks), sblock(64 * waves);
+  const size_t slds = RP_WBYTES + waves * per_wave;
+  const float4* idx4 = reinterpret_cast<const float4*>(idx_ws);
+  const unsigned char* wc = reinterpret_cast<const unsigned char*>(wa_cheb);
+  if (raw) {
+    if (products == 3)
+      hipLaunchKernelGGL((rpe_score_kernel<3, true>), sgrid, sblock, slds, (hipStream_t)stream, idx4, pos_ws, rows, wc, qp, qd,
+                         (const float*)nullptr, P, n, ldp, Q, xmax, xmax_a, scale, mpad);
+    else
+      hipLaunchKernelGGL((rpe_score_kernel<2, true>), sgrid, sblock, slds, (hipStream_t)stream, idx4, pos_ws, rows, wc, qp, qd,
+                         (const float*)nullptr, P, n, ldp, Q, xmax, xmax_a, scale, mpad);
+    SAM6D_LAUNCH_CHECK_CONT("rpe_geo_scores");
+    hipLaunchKernelGGL(rpe_listed_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, list_ws, rows, qp, P, n, ldp);
+    SAM6D_LAUNCH_CHECK("rpe_geo_scores(listed pairs)");
+  }
   hipLaunchKernelGGL(rpe_listed_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, list_ws, rows, qp, qk, n, ldp);
   SAM6D_LAUNCH_CHECK_CONT("rpe_scores(listed pairs)");
   if (products == 3)

@@ -504,3 +504,205 @@ extern "C" int sam6d_cross_attention_kv(const float* x, const float* mem, const 
   hipLaunchKernelGGL(xattn_kernel<true>, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS_KV, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention_kv");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tail of the RPE self-attention (RPEMultiHeadAttention.forward, PEM/model/transformer.py:405-416) once q, k, v exist (rpe_front)
+// and the geometric score term G[q][h][m] = q_h . proj_p(E[q, m])_h has been rebuilt (rpe_score_kernel, raw mode; listed pairs added
+// by rpe_listed_kernel):   P = softmax((q_h k_h^T + G) / 8) over the keys;   hidden[:, 64h .. 64h+64) = P v_h.
+// One workgroup per (cloud, head), the cross-attention kernel above without its projections: k_h and v_h^T become fp16 hi / lo LDS
+// images once, every 16-query group runs S^T = k_h q^T (2 k-steps x 13 key tiles), adds its G tile (one float4 per lane and tile:
+// the accumulator holds keys 16 i + 4 g + r of the lane's own query), softmax, out^T = v_h^T P^T (7 k-steps).
+// Before: a 4096-workgroup batched GEMM for q.k^T (35 us), the softmax inside the score kernel, and a second batched GEMM for P.v
+// (22 us) -- both launch-latency-bound at 197 x 197 x 64 per (cloud, head).
+struct SaArgs {
+  const float* qkv;   // (B n, 768): q | k | v
+  const float* G;     // (B n, 4, ldp) geometric score term (raw, not yet / 8)
+  float* out;         // (B n, 256)
+  int n, ldp;
+  int half;
+};
+
+__global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* regA = lds;                    // v_h^T image
+  unsigned char* kimg = lds + XA_WQ_BYTES;      // k_h image
+  float* red = reinterpret_cast<float*>(lds + XA_WQ_BYTES + XA_K_BYTES);  // 16 floats
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = a.n, m = a.n;
+  const bool half = a.half != 0;
+  constexpr int XA_EPT = (XA_MAXKEY * 64) / (XA_WAVES * 64);  // 26
+  const float* kb = a.qkv + (size_t)b * n * 768 + 256 + 64 * h;
+  const float* vb = kb + 256;
+  float kreg[XA_EPT], vreg[XA_EPT];
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {  // one burst of independent loads: element e = t + 512 i is (key e >> 6, channel e & 63)
+    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+    const bool ok = j < m;
+    kreg[i] = ok ? kb[(size_t)j * 768 + d] : 0.f;
+    vreg[i] = ok ? vb[(size_t)j * 768 + d] : 0.f;
+  }
+  // the query rows of this wave's first group are requested now as well
+  const int ngroups = (n + 15) >> 4;
+  float4 qa[2][2], qb[2][2];
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int grp = wave + XA_WAVES * gi;
+    const int tok = min(grp * 16 + fr, n - 1);
+    const float* src = a.qkv + ((size_t)b * n + tok) * 768 + 64 * h;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      qa[gi][s2] = *reinterpret_cast<const float4*>(src + 32 * s2 + 4 * fg);
+      qb[gi][s2] = *reinterpret_cast<const float4*>(src + 32 * s2 + 16 + 4 * fg);
+    }
+  }
+  // the v^T image is cleared first: its key slots >= m are multiplied by zero probabilities only, but must not hold NaN patterns
+  for (int i = t; i < XA_WQ_BYTES / 16; i += XA_WAVES * 64) reinterpret_cast<uint4*>(regA)[i] = make_uint4(0u, 0u, 0u, 0u);
+  float mk = 0.f, mv = 0.f;
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    mk = fmaxf(mk, fabsf(kreg[i]));
+    mv = fmaxf(mv, fabsf(vreg[i]));
+  }
+  mk = wave_max_dpp(mk);
+  mv = wave_max_dpp(mv);
+  if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
+  __syncthreads();
+  float sk = 0.f, sv = 0.f;
+#pragma unroll
+  for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
+  sk = xa_pow2_scale(sk);
+  sv = xa_pow2_scale(sv);
+#pragma unroll
+  for (int i = 0; i < XA_EPT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
+    {  // k_h image: every (key < 208, channel) slot is written (zeros beyond m)
+      _Float16 hi, lo;
+      sam6d_split_f16(kreg[i] * sk, hi, lo);
+      const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);
+      _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
+      const int ch = p >> 3, cl = 8 + (p >> 3);
+      row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
+      row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
+    }
+    {  // v_h^T image: row d, K = key
+      _Float16 hi, lo;
+      sam6d_split_f16(vreg[i] * sv, hi, lo);
+      const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
+      _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
+      const int ch = p >> 3, cl = 32 + (p >> 3);
+      row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
+      row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+    }
+  }
+  __syncthreads();
+
+  const float inv_k = 1.0f / sk, inv_v = (1.0f / sv) * (1.0f / 16384.0f);
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int grp = wave + XA_WAVES * gi;
+    if (grp < ngroups) {  // (wave-uniform)
+      const int tok = min(grp * 16 + fr, n - 1);
+      // G tiles of the lane's query: keys 16 i + 4 g .. + 3 (a row of ldp = 4 ceil(n / 4) floats, so a started float4 stays inside it)
+      const float* grow = a.G + (((size_t)b * n + tok) * 4 + h) * a.ldp + 4 * fg;
+      float4 gt[XA_NT];
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i)
+        gt[i] = 16 * i + 4 * fg < m ? *reinterpret_cast<const float4*>(grow + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // q / 8 (the softmax scale 1 / sqrt(64): a power of two) as split B fragments
+      half8 qh[2], ql[2];
+      float qm = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float4 u = qa[gi][s2], w = qb[gi][s2];
+        qm = fmaxf(qm, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+        qm = fmaxf(qm, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+      }
+      const float sq = xa_pow2_scale(xa_tok_max(qm * 0.125f));
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float e8[8] = {qa[gi][s2].x, qa[gi][s2].y, qa[gi][s2].z, qa[gi][s2].w, qb[gi][s2].x, qb[gi][s2].y, qb[gi][s2].z, qb[gi][s2].w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          _Float16 hi, lo;
+          sam6d_split_f16(e8[u] * 0.125f * sq, hi, lo);
+          qh[s2][u] = hi;
+          ql[s2][u] = lo;
+        }
+      }
+      f32x4 s[XA_NT];
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i) {
+        s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xa_mma<256, 8, 2>(s[i], kimg, 16 * i, qh, ql, fr, fg, half);
+      }
+      const float inv = inv_k * (1.0f / sq);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i) {
+        const float gv[4] = {gt[i].x, gt[i].y, gt[i].z, gt[i].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * i + 4 * fg + r;
+          s[i][r] = key < m ? s[i][r] * inv + gv[r] * 0.125f : -INFINITY;
+          mx = fmaxf(mx, s[i][r]);
+        }
+      }
+      mx = xa_tok_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < XA_NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[i][r] = __builtin_amdgcn_exp2f((s[i][r] - mx) * 1.4426950408889634f);
+          sum += s[i][r];
+        }
+      sum = xa_tok_sum(sum);
+      const float pscale = 16384.0f / sum;  // probabilities times 2^14 (fp16-safe), the 2^-14 is in inv_v
+      half8 ph[7], pl[7];
+#pragma unroll
+      for (int i = 0; i < 14; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = i < XA_NT ? s[i < XA_NT ? i : 0][r] * pscale : 0.f;
+          _Float16 hi, lo;
+          sam6d_split_f16(pv, hi, lo);
+          ph[i >> 1][4 * (i & 1) + r] = hi;
+          pl[i >> 1][4 * (i & 1) + r] = lo;
+        }
+      f32x4 o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        xa_mma<1024, 32, 7>(o[i], regA, 16 * i, ph, pl, fr, fg, half);
+      }
+      if (grp * 16 + fr < n) {
+        float* dst = a.out + ((size_t)b * n + tok) * 256 + 64 * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(dst + 16 * i + 4 * fg) = make_float4(o[i][0] * inv_v, o[i][1] * inv_v, o[i][2] * inv_v, o[i][3] * inv_v);
+      }
+    }
+  }
+}
+
+extern "C" int sam6d_rpe_self_attention(const float* qkv, const float* G, float* hidden, int B, int n, int ldp, void* stream) {
+  SAM6D_REQUIRE(qkv && G && hidden && B >= 0, "rpe_self_attention: null pointer");
+  SAM6D_REQUIRE(n > 0 && n <= XA_MAXKEY && ldp >= n && (ldp & 3) == 0,
+                "rpe_self_attention: needs n <= %d tokens per cloud and ldp >= n a multiple of 4 (n = %d, ldp = %d)", XA_MAXKEY, n, ldp);
+  SAM6D_REQUIRE(((((size_t)qkv) | ((size_t)G) | ((size_t)hidden)) & 15) == 0, "rpe_self_attention: pointers must be 16-byte aligned");
+  SAM6D_REQUIRE(B <= 65535, "rpe_self_attention: B <= 65535");
+  if (B == 0) return 0;
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)sattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
+    if (e != hipSuccess) {
+      sam6d_set_error("rpe_self_attention: cannot reserve %d bytes of LDS: %s", XA_LDS, hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&done);
+  }
+  SaArgs a{qkv, G, hidden, n, ldp, sam6d_half_for(2)};
+  hipLaunchKernelGGL(sattn_kernel, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("rpe_self_attention");
+}

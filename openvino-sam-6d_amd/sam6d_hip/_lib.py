@@ -39,6 +39,8 @@ SIGNATURES = {
     "sam6d_gemm_nt_b2": [c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_p],
     "sam6d_geo_outliers": [c_p, c_l, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "sam6d_rpe_scores": [c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
+    "sam6d_rpe_geo_scores": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
+    "sam6d_rpe_self_attention": [c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "sam6d_geo_outliers2": [c_p, c_l, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "sam6d_rpe_scores2": [c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
     "sam6d_transpose": [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_p],

@@ -26,7 +26,7 @@ def _s():
 class _Flags:
     """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
     ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products")
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn")
 
     def __init__(self):
         env = os.environ.get
@@ -38,6 +38,7 @@ class _Flags:
         self.score_mfma = env("SAM6D_SCORE_MFMA", "1") == "1"  # hypothesis scoring: distance products on the fp32 matrix cores
         self.bq_grid = env("SAM6D_BQ_GRID", "1") == "1"  # ball queries through the cell grid (identical indices)
         self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
+        self.self_attn = env("SAM6D_SELF_ATTN", "1") == "1"  # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
         self.rpe_products = int(env("SAM6D_RPE_PRODUCTS", "0"))  # 0: what the weight set allows (geo_cheb_a_packed); 3: always three
 
 
@@ -656,6 +657,11 @@ def rpe_self_layer_fused(x, G, L):
         qp = _empty((M, H * C), x)
         qd = _empty((M * H, 32), x)
         ldp = (n + 3) // 4 * 4
+        if _flags().self_attn and n <= 208:  # the attention kernel cuts k and v into its LDS images itself: plain q | k | v rows
+            with _Timed("rpe_front"):
+                _lib.call("sam6d_rpe_front", _p(x2), fr["img"].data_ptr(), _p(L["qkv"].b), fr["inv"][0], fr["inv"][1], fr["inv"][2],
+                          _p(qkv), _p(qp), _p(qd), M, _s())
+            return _rpe_self_tail(x, x2, G, L, qkv, qp, qd)
         vT = _empty((Bp, C, ldp), x)  # the values land transposed per cloud (the P.v operand): no transpose pass
         with _Timed("rpe_front"):
             _lib.call("sam6d_rpe_front_vt", _p(x2), fr["img"].data_ptr(), _p(L["qkv"].b), fr["inv"][0], fr["inv"][1], fr["inv"][2], _p(qkv),
@@ -675,6 +681,15 @@ def _rpe_self_tail(x, x2, G, L, qkv, qp, qd, vT=None):
     Bp, n, _ = x.shape
     M = Bp * n
     ldp = (n + 3) // 4 * 4
+    if _flags().self_attn and n <= 208:
+        # geometric score term alone, then q.k^T + softmax + P.v per (cloud, head) in one launch (xattn.hip sattn_kernel)
+        Gs = _empty((M, H, ldp), x)
+        with _Timed("rpe_score_kernel"):
+            _lib.call("sam6d_rpe_geo_scores", _p(G.idx), _p(G.pos), _p(G.keep[1]), _p(G.rows), G.wa_cheb, float(GEO_XMAX),
+                      float(G.xmax_a), int(G.products), _p(qp), _p(qd), _p(Gs), M, n, ldp, _s())
+        hid = _empty((M, C), x)
+        _lib.call("sam6d_rpe_self_attention", _p(qkv), _p(Gs), _p(hid), Bp, n, ldp, _s())
+        return _post_attention(hid, x2, L).reshape(Bp, n, C)
     qk = _empty((M, H, ldp), x)
     P = _empty((M, H, ldp), x)
     gemm_b2(qkv, qkv, qk, n, n, 64, 3 * C, 3 * C, H * ldp, Bp, n * 3 * C, n * 3 * C, n * H * ldp, H, 64, 64, ldp, w_off=C)

@@ -299,6 +299,35 @@ def test_cross_attention_kv_vs_fp64(dev, B, n, m, xs):
     assert float((out2.cpu().double() - got).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,n,qs,gs", [(2, 197, 1.0, 1.0), (3, 50, 1.0, 1.0), (1, 4, 1.0, 1.0), (2, 208, 1.0, 1.0), (2, 197, 300.0, 1.0),
+                                       (2, 130, 1e-3, 40.0), (5, 16, 1.0, 1.0)])
+def test_rpe_self_attention_vs_fp64(dev, B, n, qs, gs):
+    """sam6d_rpe_self_attention: hidden_h = softmax((q_h k_h^T + G) / 8) v_h for the four heads of one RPE self layer
+    (RPEMultiHeadAttention.forward, PEM/model/transformer.py:405-416, with the geometric term G given) against a float64 recompute;
+    qs scales the queries (and 1 / qs the keys), gs the geometric term; rows of G are ldp = 4 ceil(n / 4) floats apart."""
+    from sam6d_hip import _lib
+    gen = torch.Generator().manual_seed(17 * B + n)
+    ldp = (n + 3) // 4 * 4
+    qkv = torch.randn(B * n, 768, generator=gen)
+    qkv[:, :256] *= qs
+    qkv[:, 256:512] /= qs
+    qkv[3 % (B * n), :256] *= 30.0  # one query row far above the others
+    G = torch.full((B * n, 4, ldp), float("nan"))
+    G[:, :, :n] = torch.randn(B * n, 4, n, generator=gen) * gs
+    G[:, :, n:] = 1e30  # padding of a row: never read as a key
+    d = lambda t: t.double()
+    q, k, v = (d(qkv[:, i * 256:(i + 1) * 256]).reshape(B, n, 4, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(-1, -2) + d(G[:, :, :n]).reshape(B, n, 4, n).permute(0, 2, 1, 3)) / 8.0
+    want = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * n, 256)
+    out = torch.full((B * n, 256), float("nan"), device=dev)
+    qd, Gd = qkv.to(dev), G.to(dev)
+    _lib.call("sam6d_rpe_self_attention", qd.data_ptr(), Gd.data_ptr(), out.data_ptr(), B, n, ldp, torch.cuda.current_stream().cuda_stream)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = float((got - want).abs().max())
+    assert err < 3e-6 * max(1.0, float(want.abs().max())), "rpe self attention vs fp64: %.3e" % err
+
+
 def test_geometric_transformer_writes_stacked_halves(dev):
     """The two sequential cross layers write their halves of the stacked (2B, n, 256) result in place: equal to the layers called one
     by one (PEM/model/transformer.py:517-524: feats1 attends to the already-updated feats0)."""

@@ -713,6 +713,36 @@ def test_rpe_stage1_two_and_three_products(dev, W, sigma_a, forced):
     assert torch.isfinite(got).all() and d < 2e-5
 
 
+def test_rpe_self_layer_one_launch_attention_equals_gemm_path(dev, W):
+    """The default RPE self layer (geometric scores, then q.k^T + softmax + P.v in one launch per (cloud, head)) against the same
+    layer with the q.k^T / P.v GEMMs and the softmax inside the score kernel (SAM6D_SELF_ATTN=0)."""
+    import os
+    from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the fused RPE path is the default (fp16x3) mode")
+    gen = torch.Generator().manual_seed(5)
+    B, n = 4, 197
+    pts = (torch.rand(B, n, 3, generator=gen) - 0.5) * 1.2
+    pts[:, 0] = 100.0
+    x = torch.randn(B, n, 256, generator=gen).to(dev)
+    L = W.coarse["blocks"][0]["self"]
+    G = pem.geo_context(pts.to(dev), W)
+    outs = []
+    old = os.environ.get("SAM6D_SELF_ATTN")
+    try:
+        for v in ("1", "0"):
+            os.environ["SAM6D_SELF_ATTN"] = v
+            outs.append(pem.rpe_self_layer(x, G, L).cpu())
+    finally:
+        if old is None:
+            os.environ.pop("SAM6D_SELF_ATTN", None)
+        else:
+            os.environ["SAM6D_SELF_ATTN"] = old
+    d = float((outs[0] - outs[1]).abs().max())
+    print("\none-launch attention vs GEMM path: max abs diff %.2e (scale %.1f)" % (d, float(outs[1].abs().max())))
+    assert torch.isfinite(outs[0]).all() and d < 1e-5
+
+
 def test_rpe_fused_range_guard(dev, sd):
     """Weights whose projected angular embedding could leave the fp16 range of the score kernel's second contraction are detected on
     the host (sum of |Chebyshev coefficients| per channel) and keep the materialised-embedding path; weights whose x1024 images would
