@@ -356,6 +356,15 @@ size_t sam6d_fine_match_workspace_bytes(int B);
 size_t sam6d_fine_match_workspace_bytes_n(int B, int n);
 int sam6d_fine_match(const float* f, int B, int n, float temp, const float* pts2, int* label1, int* label2, float* pred,
                      float* weight, void* ws, size_t ws_bytes, void* stream);
+/* The same with the operands already prepared: sam6d_linear_norm_split computes y = x W^T + b for the M rows of x (M, 256), W as the
+ * 8-panel image of sam6d_pack_panels (256 rows, k0 = 0, ksteps = 8, scale s; inv_w_scale = 1 / s) -- FinePointMatching's out_proj,
+ * PEM/model/fine_point_matching.py:70-72 -- and writes fh | fl (M, 256) fp16 = hi / lo halves of (y / max(|y|, 1e-12)) * 2^10, the
+ * F.normalize of compute_feature_similarity (PEM/utils/model_utils.py:141-142) and the operand split of the similarity product in one
+ * pass; sam6d_fine_match_split takes those halves instead of f (same workspace size). */
+int sam6d_linear_norm_split(const float* x, const void* wimage, const float* bias, float inv_w_scale, void* fh, void* fl, long M,
+                            void* stream);
+int sam6d_fine_match_split(const void* fh, const void* fl, int B, int n, float temp, const float* pts2, int* label1, int* label2,
+                           float* pred, float* weight, void* ws, size_t ws_bytes, void* stream);
 /* Fine soft-assignment reduction (PEM/utils/model_utils.py:325-331): pred (B,R-1,3), weight (B,R-1). */
 int sam6d_fine_assign(const float* att, int B, int R, int C, const float* rmax, const float* rsum, const float* cmax,
                       const float* csum, const int* label1, const int* label2, const float* pts2, float* pred,

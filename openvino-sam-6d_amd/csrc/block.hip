@@ -1079,6 +1079,140 @@ static int rpe_front_launch(const float* x, const void* wimage, const float* bia
   SAM6D_LAUNCH_CHECK("rpe_front");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// out_proj + F.normalize + the operand split of the fine similarity in one pass over the dense tokens
+// (FinePointMatching.forward: out_proj, PEM/model/fine_point_matching.py:70-72; compute_feature_similarity: F.normalize(dim=2),
+// PEM/utils/model_utils.py:141-142):   y = x W^T + b;   fh | fl = fp16 hi / lo of (y / max(|y|, 1e-12)) * 2^10
+// -- what sam6d_gemm_nt followed by finematch.hip's fm_prep_kernel produce (a 134 MB fp32 intermediate written and read back at
+// B = 32).  One workgroup = 64 token rows on four computing waves + four loader waves (8 panels, two per ring slot), the same
+// register-chained transposed product as token_block_kernel; rows are read non-temporally (each exactly once).
+struct OsArgs {
+  const float* x;            // (M, 256)
+  const unsigned char* wimg; // sam6d_pack_panels(W, 256 rows, k0 = 0, ksteps = 8): 8 panels
+  const float* bias;         // (256)
+  _Float16* fh;              // (M, 256)
+  _Float16* fl;
+  long M;
+  float inv_w;               // 1 / pack scale of W
+  int half;
+};
+
+__global__ __launch_bounds__(512, 1) void out_split_kernel(OsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  constexpr int SLOT = 2 * TB_PANEL_BYTES;
+  if (wave >= 4) {  // loader waves: step T = panels 2 T, 2 T + 1 into slot T & 1
+    auto dma_step = [&](int T) {
+      const unsigned char* src = a.wimg + (size_t)T * SLOT;
+      unsigned char* dst = lds + (T & 1) * SLOT;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int pc = (wave - 4) + 4 * k;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                         (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
+      }
+    };
+    dma_step(0);
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (T + 1 < 4) dma_step(T + 1);
+    }
+    return;
+  }
+  const long r0 = (long)blockIdx.x * 64 + wave * 16 + fr;
+  const bool valid = r0 < a.M;
+  const long row = valid ? r0 : a.M - 1;
+  half8 xh[8], xl[8];
+  float sx;
+  {
+    const float* src = a.x + (size_t)row * 256;
+    f32x4 va[8], vb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      va[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 32 * s + 4 * fg));
+      vb[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + 32 * s + 16 + 4 * fg));
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fabsf(va[s][r]), fabsf(vb[s][r])));
+    sx = pow2_scale_for(tok_max(m));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float e[8] = {va[s][0], va[s][1], va[s][2], va[s][3], vb[s][0], vb[s][1], vb[s][2], vb[s][3]};
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        unsigned hi, lo;
+        sam6d_split2_f16(e[u] * sx, e[u + 1] * sx, hi, lo);
+        const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+        const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+        xh[s][u] = h2[0];
+        xh[s][u + 1] = h2[1];
+        xl[s][u] = l2[0];
+        xl[s][u + 1] = l2[1];
+      }
+    }
+  }
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool half = a.half != 0;
+  tb_static_for<0, 8>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if constexpr ((j & 1) == 0) __syncthreads();  // step j / 2 has landed (loader waves) and is published
+    const unsigned p = pan_lds + ((j >> 1) & 1) * SLOT + (j & 1) * TB_PANEL_BYTES;
+    tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
+  });
+  const float inv = a.inv_w * (1.0f / sx);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float4 bb = *reinterpret_cast<const float4*>(a.bias + 16 * i + 4 * fg);
+    acc[i][0] = acc[i][0] * inv + bb.x;
+    acc[i][1] = acc[i][1] * inv + bb.y;
+    acc[i][2] = acc[i][2] * inv + bb.z;
+    acc[i][3] = acc[i][3] * inv + bb.w;
+    ss += (acc[i][0] * acc[i][0] + acc[i][1] * acc[i][1]) + (acc[i][2] * acc[i][2] + acc[i][3] * acc[i][3]);
+  }
+  const float d = fmaxf(sqrtf(tok_sum(ss)), 1e-12f);
+  if (valid) {
+    _Float16* oh = a.fh + (size_t)row * 256 + 4 * fg;
+    _Float16* ol = a.fl + (size_t)row * 256 + 4 * fg;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      unsigned h01, l01, h23, l23;
+      sam6d_split2_f16((acc[i][0] / d) * 1024.0f, (acc[i][1] / d) * 1024.0f, h01, l01);
+      sam6d_split2_f16((acc[i][2] / d) * 1024.0f, (acc[i][3] / d) * 1024.0f, h23, l23);
+      *reinterpret_cast<tb_u2*>(oh + 16 * i) = tb_u2{h01, h23};
+      *reinterpret_cast<tb_u2*>(ol + 16 * i) = tb_u2{l01, l23};
+    }
+  }
+}
+
+extern "C" int sam6d_linear_norm_split(const float* x, const void* wimage, const float* bias, float inv_w_scale, void* fh, void* fl,
+                                       long M, void* stream) {
+  SAM6D_REQUIRE(x && wimage && bias && fh && fl && M >= 0 && inv_w_scale > 0.f, "linear_norm_split: bad arguments");
+  SAM6D_REQUIRE(((((size_t)x) | ((size_t)wimage) | ((size_t)bias) | ((size_t)fh) | ((size_t)fl)) & 15) == 0,
+                "linear_norm_split: pointers must be 16-byte aligned");
+  if (M == 0) return 0;
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)out_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TB_PANEL_BYTES);
+    if (e != hipSuccess) {
+      sam6d_set_error("linear_norm_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&done);
+  }
+  OsArgs a{x, (const unsigned char*)wimage, bias, (_Float16*)fh, (_Float16*)fl, M, inv_w_scale, sam6d_half_for(1)};
+  hipLaunchKernelGGL(out_split_kernel, dim3((unsigned)((M + 63) / 64)), dim3(512), 4 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("linear_norm_split");
+}
+
 #define TB_LDS_BYTES(NBUF) ((NBUF) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 #define TB_LDS_BYTES2(NBUF, PSTEP) ((NBUF) * (PSTEP) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 

@@ -515,21 +515,37 @@ extern "C" size_t sam6d_fine_match_workspace_bytes_n(int B, int n) {
   return (n > 1 && (n - 1) % FM_CHUNK == 0) ? fm_workspace_bytes(B, n - 1) : 0;
 }
 
+static int fm_run(const float* f, const _Float16* fh_in, const _Float16* fl_in, int B, int n, float temp, const float* pts2,
+                  int* label1, int* label2, float* pred, float* weight, void* ws, size_t ws_bytes, void* stream);
 extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const float* pts2, int* label1, int* label2, float* pred,
                                 float* weight, void* ws, size_t ws_bytes, void* stream) {
-  SAM6D_REQUIRE(f && pts2 && label1 && label2 && pred && weight && ws, "fine_match: null pointer");
+  SAM6D_REQUIRE(f, "fine_match: null pointer");
+  return fm_run(f, nullptr, nullptr, B, n, temp, pts2, label1, label2, pred, weight, ws, ws_bytes, stream);
+}
+extern "C" int sam6d_fine_match_split(const void* fh, const void* fl, int B, int n, float temp, const float* pts2, int* label1,
+                                      int* label2, float* pred, float* weight, void* ws, size_t ws_bytes, void* stream) {
+  SAM6D_REQUIRE(fh && fl && ((((size_t)fh) | ((size_t)fl)) & 15) == 0, "fine_match_split: fh / fl must be 16-byte aligned pointers");
+  return fm_run(nullptr, (const _Float16*)fh, (const _Float16*)fl, B, n, temp, pts2, label1, label2, pred, weight, ws, ws_bytes, stream);
+}
+
+// f: the out_proj features (fm_prep_kernel normalises and splits them into the workspace), or fh_in / fl_in: the split halves as
+// sam6d_linear_norm_split leaves them
+static int fm_run(const float* f, const _Float16* fh_in, const _Float16* fl_in, int B, int n, float temp, const float* pts2,
+                  int* label1, int* label2, float* pred, float* weight, void* ws, size_t ws_bytes, void* stream) {
+  SAM6D_REQUIRE(pts2 && label1 && label2 && pred && weight && ws, "fine_match: null pointer");
   SAM6D_REQUIRE(n == 2049 || n == 4097, "fine_match: built for n = 2049 or 4097 tokens per cloud (got %d)", n);
   SAM6D_REQUIRE(B >= 0 && B <= 4096 && temp > 0.f, "fine_match: bad sizes");
   const int np = n - 1, chunks = np / FM_CHUNK, lde = FM_LDE(np), slots = FM_SLOTS(np), slabs = FM_SLABS(np), nt = np / 128;
   SAM6D_REQUIRE(ws_bytes >= fm_workspace_bytes(B, np), "fine_match: workspace too small");
   SAM6D_REQUIRE((((size_t)ws | (size_t)f | (size_t)pts2 | (size_t)label2) & 15) == 0, "fine_match: pointers must be 16-byte aligned");
+  SAM6D_REQUIRE(f || (fh_in && fl_in), "fine_match: no features");
   SAM6D_REQUIRE((long)cdiv(B, 8) * 8 * nt * nt < 2147483647L, "fine_match: too many tiles for one launch");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const size_t rows = (size_t)2 * B * n;
   unsigned char* p = (unsigned char*)ws;
-  _Float16* fh = (_Float16*)p; p += fm_align(rows * FM_C * 2);
-  _Float16* fl = (_Float16*)p; p += fm_align(rows * FM_C * 2);
+  const _Float16* fh = fh_in ? fh_in : (_Float16*)p; p += fm_align(rows * FM_C * 2);
+  const _Float16* fl = fl_in ? fl_in : (_Float16*)p; p += fm_align(rows * FM_C * 2);
   float* E = (float*)p; p += fm_align((size_t)B * n * lde * 4 + 64);
   float* rowpart = (float*)p; p += fm_align((size_t)B * np * slots * 4);
   float* colpart = (float*)p; p += fm_align((size_t)B * np * slots * 4);
@@ -546,7 +562,7 @@ extern "C" int sam6d_fine_match(const float* f, int B, int n, float temp, const 
   // E = exp(att - c) = exp2(acc * k1 - k2): acc carries the operand scale 2^20, att = acc / (2^20 temp), c = 1 / temp
   const float log2e = 1.4426950408889634f;
   const float k1 = log2e / (FM_OPSCALE * FM_OPSCALE * temp), k2 = log2e / temp;
-  hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, fh, fl);
+  if (!fh_in) hipLaunchKernelGGL(fm_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, f, (long)rows, (_Float16*)fh, (_Float16*)fl);
   hipLaunchKernelGGL(fm_sim_kernel, dim3((unsigned)(cdiv(B, 8) * 8 * nt * nt)), dim3(256), 0, s, fh, fl, B, k1, k2, E, rowpart, colpart,
                      sam6d_half_for(3), np);
   hipLaunchKernelGGL(fm_bg_kernel, dim3(cdiv(2 * np + 1, 4 * FM_BG_PER_WAVE), B), dim3(256), 0, s, fh, fl, B, k1, k2, E, np);

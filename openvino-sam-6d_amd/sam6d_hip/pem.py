@@ -26,7 +26,7 @@ def _s():
 class _Flags:
     """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
     ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn")
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn", "fused_out")
 
     def __init__(self):
         env = os.environ.get
@@ -39,6 +39,7 @@ class _Flags:
         self.bq_grid = env("SAM6D_BQ_GRID", "1") == "1"  # ball queries through the cell grid (identical indices)
         self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
         self.self_attn = env("SAM6D_SELF_ATTN", "1") == "1"  # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
+        self.fused_out = self.fused_block and env("SAM6D_FUSED_OUT", "1") == "1"  # fine out_proj + normalize + operand split in one pass
         self.rpe_products = int(env("SAM6D_RPE_PRODUCTS", "0"))  # 0: what the weight set allows (geo_cheb_a_packed); 3: always three
 
 
@@ -1041,19 +1042,37 @@ def compute_fine_Rt(att, pts1, pts2, model, radius, dis_thres=0.15):
 
 @on_tensor_device
 def fine_match(f, B, n, temp, pts2):
-    """f (2B*n, 256) out_proj outputs [scene clouds; template clouds] -> label1, label2 (B,n-1) i32, pred (B,n-1,3), weight (B,n-1)
+    """f (2B*n, 256) out_proj outputs [scene clouds; template clouds] -- or the pair (fh, fl) of sam6d_linear_norm_split -- -> label1,
+    label2 (B,n-1) i32, pred (B,n-1,3), weight (B,n-1)
     (compute_feature_similarity + the soft-assignment head of compute_fine_Rt, PEM/utils/model_utils.py:131-153, 308-331)."""
-    l1 = _empty((B, n - 1), f, torch.int32)
-    l2 = _empty((B, n - 1), f, torch.int32)
-    pred = _empty((B, n - 1, 3), f)
-    wgt = _empty((B, n - 1), f)
+    l1 = _empty((B, n - 1), pts2, torch.int32)
+    l2 = _empty((B, n - 1), pts2, torch.int32)
+    pred = _empty((B, n - 1, 3), pts2)
+    wgt = _empty((B, n - 1), pts2)
     nbytes = int(_lib.load().sam6d_fine_match_workspace_bytes_n(B, n))
     if nbytes == 0:
         raise ValueError("fine_match: n = %d tokens per cloud (2049 or 4097 are built)" % n)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=f.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts2.device)
     with _Timed("fine_match"):
-        _lib.call("sam6d_fine_match", _p(f), B, n, float(temp), _p(pts2), _p(l1), _p(l2), _p(pred), _p(wgt), ws.data_ptr(), nbytes, _s())
+        if isinstance(f, tuple):
+            _lib.call("sam6d_fine_match_split", f[0].data_ptr(), f[1].data_ptr(), B, n, float(temp), _p(pts2), _p(l1), _p(l2), _p(pred),
+                      _p(wgt), ws.data_ptr(), nbytes, _s())
+        else:
+            _lib.call("sam6d_fine_match", _p(f), B, n, float(temp), _p(pts2), _p(l1), _p(l2), _p(pred), _p(wgt), ws.data_ptr(), nbytes, _s())
     return l1, l2, pred, wgt
+
+
+def linear_norm_split(x, L, img=None):
+    """x (M,256), L a 256 -> 256 Linear (img: its panel image, pack_cross_query(L)): (fh, fl) fp16 halves of normalize(L(x)) * 2^10 --
+    out_proj, F.normalize and the operand split of the fine similarity in one pass (block.hip out_split_kernel)."""
+    M = x.shape[0]
+    if img is None:
+        img = pack_cross_query(L)
+    fh = torch.empty(M * C, dtype=torch.float16, device=x.device)
+    fl = torch.empty(M * C, dtype=torch.float16, device=x.device)
+    with _Timed("linear_norm_split"):
+        _lib.call("sam6d_linear_norm_split", _p(x), img["img"].data_ptr(), _p(L.b), float(img["inv"]), fh.data_ptr(), fl.data_ptr(), M, _s())
+    return fh, fl
 
 
 def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.15, return_aux=False):
@@ -1061,8 +1080,8 @@ def compute_fine_Rt_fused(f, B, n, temp, pts1, pts2, model, radius, dis_thres=0.
     pts2 = pts2.contiguous()
     l1, l2, pred, wgt = fine_match(f, B, n, temp, pts2)
     R, t = weighted_procrustes(pred, pts1, wgt, 0.0)
-    cnt = _empty((B, 2), f)
-    score = _empty((B,), f)
+    cnt = _empty((B, 2), pts2)
+    score = _empty((B,), pts2)
     _lib.call("sam6d_fine_score", _p(pts1), _p(R), _p(t), _p(model), _p(radius), _p(l1), B, n - 1, model.shape[1], float(dis_thres),
               _p(cnt), _p(score), _s())
     if return_aux:
@@ -1195,7 +1214,12 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
         D = sparse_to_dense_transformer(D, E, fps_idx, blk)
     if fused_fine and N in (2048, 4096) and _fused_block():
         # similarity + soft assignment as one pipeline: the (B, 2049, 2049) matrix is written once and read twice (finematch.hip)
-        f = linear(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"])
+        if _flags().fused_out and _flags().mode >= 1:
+            if "out_img" not in W.fine:
+                W.fine["out_img"] = pack_cross_query(W.fine["out_proj"])
+            f = linear_norm_split(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"], W.fine["out_img"])
+        else:
+            f = linear(D.reshape(2 * B * (N + 1), C), W.fine["out_proj"])
         return compute_fine_Rt_fused(f, B, N + 1, cfg["temp"], dp[:B], dp[B:], model, radius, cfg["dis_thres"], return_aux)
     att = feature_similarity(D, B, N + 1, W.fine["out_proj"], cfg["temp"])
     R, t, score = compute_fine_Rt(att, dp[:B], dp[B:], model, radius, cfg["dis_thres"])
@@ -1223,6 +1247,8 @@ def _ensure_w16(W):
         walk(part)
     # the RPE-front weight images of every self layer too (rpe_self_layer_fused would build them on first use -- with micro-batching
     # on whichever slice's stream got there first, while another slice's stream could already launch with the cached image)
+    if getattr(W, "fine", None) and "out_proj" in W.fine and "out_img" not in W.fine:
+        W.fine["out_img"] = pack_cross_query(W.fine["out_proj"])
     dcT = geo_dcT(W)
     for part in (getattr(W, "coarse", None), getattr(W, "fine", None)):
         for blk in (part or {}).get("blocks", []):

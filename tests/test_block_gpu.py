@@ -328,6 +328,27 @@ def test_rpe_self_attention_vs_fp64(dev, B, n, qs, gs):
     assert err < 3e-6 * max(1.0, float(want.abs().max())), "rpe self attention vs fp64: %.3e" % err
 
 
+@pytest.mark.parametrize("M,xs", [(64 * 5, 1.0), (130, 1.0), (1, 1.0), (4098, 30.0), (257, 1e-4)])
+def test_linear_norm_split_vs_fp64(dev, M, xs):
+    """sam6d_linear_norm_split: fh + fl = normalize(x W^T + b) * 2^10 (out_proj + F.normalize + the operand split of the fine similarity,
+    PEM/model/fine_point_matching.py:70-72, PEM/utils/model_utils.py:141-142) against float64."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(M)
+    w = (torch.rand(256, 256, generator=gen) * 2 - 1) / 16
+    b = (torch.rand(256, generator=gen) * 2 - 1) / 16 * xs
+    x = torch.randn(M, 256, generator=gen) * xs
+    x[M // 2] *= 40.0
+    L = pem.Linear(w.to(dev), b.to(dev))
+    fh, fl = pem.linear_norm_split(x.to(dev).contiguous(), L)
+    got = (fh.float() + fl.float()).cpu().double().reshape(M, 256) / 1024.0
+    y = x.double() @ w.double().t() + b.double()
+    want = y / y.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    err = float((got - want).abs().max())
+    assert torch.isfinite(got).all() and err < 3e-7, "linear + normalize + split vs fp64: %.3e" % err
+    # the lo half is a genuine second half: at most 2^-10 of the hi half's magnitude scale, and the pair carries >= 21 bits
+    assert float(fl.float().abs().max()) <= float(fh.float().abs().max()) * 2.0 ** -10 + 1e-3
+
+
 def test_geometric_transformer_writes_stacked_halves(dev):
     """The two sequential cross layers write their halves of the stacked (2B, n, 256) result in place: equal to the layers called one
     by one (PEM/model/transformer.py:517-524: feats1 attends to the already-updated feats0)."""
