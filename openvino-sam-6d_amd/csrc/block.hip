@@ -1097,30 +1097,38 @@ struct OsArgs {
   int half;
 };
 
-__global__ __launch_bounds__(512, 1) void out_split_kernel(OsArgs a) {
+// LOADERS = 4, PSTEP = 2: four loader waves, two panels per ring slot (one workgroup per CU: 128 KB of LDS); LOADERS = 0, PSTEP = 1:
+// the computing waves issue their own DMA, one panel per slot (64 KB: two workgroups per CU, one's row loads / stores beside the
+// other's products) -- the shape for this pure streaming pass.
+template <int LOADERS, int PSTEP>
+__global__ __launch_bounds__((4 + LOADERS) * 64, LOADERS ? 1 : 2) void out_split_kernel(OsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  constexpr int SLOT = 2 * TB_PANEL_BYTES;
-  if (wave >= 4) {  // loader waves: step T = panels 2 T, 2 T + 1 into slot T & 1
-    auto dma_step = [&](int T) {
-      const unsigned char* src = a.wimg + (size_t)T * SLOT;
-      unsigned char* dst = lds + (T & 1) * SLOT;
+  constexpr int SLOT = PSTEP * TB_PANEL_BYTES, NSTEP = 8 / PSTEP;
+  auto dma_step = [&](int T) {  // step T = PSTEP panels into slot T & 1, dealt to the four issuing waves
+    const unsigned char* src = a.wimg + (size_t)T * SLOT;
+    unsigned char* dst = lds + (T & 1) * SLOT;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int pc = (wave - 4) + 4 * k;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
-                                         (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
-      }
-    };
-    dma_step(0);
-#pragma unroll
-    for (int T = 0; T < 4; ++T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (T + 1 < 4) dma_step(T + 1);
+    for (int k = 0; k < 8 * PSTEP; ++k) {
+      const int pc = (LOADERS ? wave - 4 : wave) + 4 * k;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                       (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
     }
-    return;
+  };
+  if constexpr (LOADERS > 0) {
+    if (wave >= 4) {
+      dma_step(0);
+#pragma unroll
+      for (int T = 0; T < NSTEP; ++T) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (T + 1 < NSTEP) dma_step(T + 1);
+      }
+      return;
+    }
+  } else {
+    dma_step(0);
   }
   const long r0 = (long)blockIdx.x * 64 + wave * 16 + fr;
   const bool valid = r0 < a.M;
@@ -1163,8 +1171,12 @@ __global__ __launch_bounds__(512, 1) void out_split_kernel(OsArgs a) {
   const bool half = a.half != 0;
   tb_static_for<0, 8>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    if constexpr ((j & 1) == 0) __syncthreads();  // step j / 2 has landed (loader waves) and is published
-    const unsigned p = pan_lds + ((j >> 1) & 1) * SLOT + (j & 1) * TB_PANEL_BYTES;
+    if constexpr (j % PSTEP == 0) {  // step j / PSTEP has landed and is published; the slot of the step before is free
+      if constexpr (LOADERS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if constexpr (LOADERS == 0 && j / PSTEP + 1 < NSTEP) dma_step(j / PSTEP + 1);
+    }
+    const unsigned p = pan_lds + ((j / PSTEP) & 1) * SLOT + (j % PSTEP) * TB_PANEL_BYTES;
     tb_mma<8>(acc[2 * j], acc[2 * j + 1], p, xh, xl, fr, fg, half);
   });
   const float inv = a.inv_w * (1.0f / sx);
@@ -1201,7 +1213,9 @@ extern "C" int sam6d_linear_norm_split(const float* x, const void* wimage, const
   if (M == 0) return 0;
   static unsigned long long done = 0;
   if (sam6d_first_use_on_device(&done)) {
-    hipError_t e = hipFuncSetAttribute((const void*)out_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TB_PANEL_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)out_split_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TB_PANEL_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)out_split_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TB_PANEL_BYTES);
     if (e != hipSuccess) {
       sam6d_set_error("linear_norm_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return (int)e;
@@ -1209,7 +1223,16 @@ extern "C" int sam6d_linear_norm_split(const float* x, const void* wimage, const
     sam6d_setup_done_on_device(&done);
   }
   OsArgs a{x, (const unsigned char*)wimage, bias, (_Float16*)fh, (_Float16*)fl, M, inv_w_scale, sam6d_half_for(1)};
-  hipLaunchKernelGGL(out_split_kernel, dim3((unsigned)((M + 63) / 64)), dim3(512), 4 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  static int shape = -1;  // SAM6D_OUT_SPLIT_LOADERS=1: the one-workgroup-per-CU shape with loader waves (A/B runs)
+  if (shape < 0) {
+    const char* e = getenv("SAM6D_OUT_SPLIT_LOADERS");
+    shape = (e && e[0] == '1') ? 1 : 0;
+  }
+  const dim3 g((unsigned)((M + 63) / 64));
+  if (shape)
+    hipLaunchKernelGGL((out_split_kernel<4, 2>), g, dim3(512), 4 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((out_split_kernel<0, 1>), g, dim3(256), 2 * TB_PANEL_BYTES, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("linear_norm_split");
 }
 

@@ -25,7 +25,8 @@ sel = [("rpe_score_kernel", "rpe_score_kernel<2, true>", "one RPE layer over 64 
        ("sattn_kernel (sam6d_rpe_self_attention)", "sattn_kernel", "q.k^T + G, softmax, P.v per (cloud, head): q | k | v rows and the score term read, hidden written", 12608 * (768 + 800 + 256) * 4),
        ("rpe_front_kernel", "rpe_front_kernel", "qkv + folds", None), ("rpe_listed_kernel", "rpe_listed_kernel", "listed pairs", None),
        ("fm_sim_kernel", "fm_sim_kernel", "fine-match pipeline", 671613952), ("fm_labels_kernel", "fm_labels_kernel", "fine-match pipeline", None),
-       ("fm_assign_kernel", "fm_assign_kernel", "fine-match pipeline", None), ("fm_prep_kernel", "fm_prep_kernel", "fine-match pipeline", None),
+       ("fm_assign_kernel", "fm_assign_kernel", "fine-match pipeline", None),
+       ("out_split_kernel (sam6d_linear_norm_split)", "out_split_kernel", "out_proj + normalize + operand split: D read once, fp16 hi / lo written", 2 * 32 * 2049 * 256 * 8),
        ("fm_bg_kernel", "fm_bg_kernel", "fine-match pipeline", None), ("fm_merge_sums_kernel", "fm_merge_sums_kernel", "fine-match pipeline", None),
        ("fm_merge_labels_kernel", "fm_merge_labels_kernel", "fine-match pipeline", None),
        ("score_hyp_mfma_kernel", "score_hyp_mfma_kernel", "hypothesis scoring", None), ("pe_mlp_max_h3_kernel", "pe_mlp_max_h3_kernel", "PE MLP + max", None),

@@ -89,10 +89,11 @@ ops = {
     "cross_layer": lambda: pem.cross_layer(S[:B], S[B:], T["cross"]),
     "geo_transformer_block": lambda: pem.geometric_transformer(S, G, T),
     "dense_layer": lambda: pem.linear_transformer_layer(DD, S, FT),
+    "out_split": lambda: pem.linear_norm_split(DD.reshape(-1, 256), W.fine["out_proj"], W.fine["out_img"]),
     "kv_linear_6304": lambda: pem.linear(x2[:6304], T["cross"]["kv"]),
 }
-DD = torch.randn(2 * B, 2049, 256, generator=g).to(dev) if "dense_layer" in sys.argv else None
+DD = torch.randn(2 * B, 2049, 256, generator=g).to(dev) if ("dense_layer" in sys.argv or "out_split" in sys.argv) else None
 FT = W.fine["blocks"][0]["dense"] if "dense" in W.fine["blocks"][0] else None
-want = sys.argv[1:] or [k for k in ops if k != "dense_layer"]
+want = sys.argv[1:] or [k for k in ops if k not in ("dense_layer", "out_split")]
 for name in want:
     timeit(name, ops[name])
