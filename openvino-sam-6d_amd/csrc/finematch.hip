@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void fm_prep_kernel(const float* __restrict__ 
 // E tile (128 x 128) = exp2(acc * k1 - k2), acc = sum_k f1[n][k] f2[m][k] (fp16 x3 split products, fp32 accumulate), for the dense
 // points n, m = 1 .. 2048 of proposal b.  4 waves in a 2 x 2 grid, each 64 x 64 (2 x 2 tiles of v_mfma_f32_32x32x16_f16).
 // Operand staging: 16-byte global loads of the pre-split halves -> ds_write_b128, next K chunk prefetched into registers.
+// (Measured and removed, round 3: staging by LDS-DMA -- 1 KiB pieces of 16 rows x 64 B with a per-lane swizzled source chunk so that the
+// linear LDS image is conflict-free, two 32 KB slots, one barrier per chunk: the whole fine match 0.575 ms against 0.551 ms; two
+// workgroups per CU instead of three to four, and eight DMA pieces of ~45 issue cycles per wave and chunk.)
 #define FM_BK 32
 #define FM_LD 40  // halves per LDS row (80 B): the ds_read_b128 fragment reads of 16 consecutive rows are conflict-free
 __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B,
