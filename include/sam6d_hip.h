@@ -356,7 +356,16 @@ size_t sam6d_fine_match_workspace_bytes(int B);
 size_t sam6d_fine_match_workspace_bytes_n(int B, int n);
 int sam6d_fine_match(const float* f, int B, int n, float temp, const float* pts2, int* label1, int* label2, float* pred,
                      float* weight, void* ws, size_t ws_bytes, void* stream);
-/* The same with the operands already prepared: sam6d_linear_norm_split computes y = x W^T + b for the M rows of x (M, 256), W as the
+/* y = x W^T + b for M token rows of 256 channels on the panel kernel (the sparse-token projections: CoarsePointMatching's in_proj /
+ * out_proj, PEM/model/coarse_point_matching.py:35-38, 61; [proj_k; proj_v] of a LinearAttention layer's memory tokens,
+ * PEM/model/transformer.py:556-558).  wimage = sam6d_pack_panels(W, 32 npanels rows, k0 = 0, ksteps = 8, scale s), npanels 8 or 16
+ * (256 or 512 outputs), inv_w_scale = 1 / s, bias may be null.  Row R = (cloud R / rows_per_cloud, token R % rows_per_cloud) is read
+ * at row cloud * x_cloud_rows + x_row0 + token of x and written at row cloud * out_cloud_rows + out_row0 + token of out (32 npanels
+ * floats per row): the bg slot of a token buffer is skipped in place on either side. */
+int sam6d_rows_linear(const float* x, const void* wimage, int npanels, const float* bias, float inv_w_scale, float* out, long M,
+                      int rows_per_cloud, long x_cloud_rows, long x_row0, long out_cloud_rows, long out_row0, void* stream);
+
+/* sam6d_fine_match with the operands already prepared: sam6d_linear_norm_split computes y = x W^T + b for the M rows of x (M, 256), W as the
  * 8-panel image of sam6d_pack_panels (256 rows, k0 = 0, ksteps = 8, scale s; inv_w_scale = 1 / s) -- FinePointMatching's out_proj,
  * PEM/model/fine_point_matching.py:70-72 -- and writes fh | fl (M, 256) fp16 = hi / lo halves of (y / max(|y|, 1e-12)) * 2^10, the
  * F.normalize of compute_feature_similarity (PEM/utils/model_utils.py:141-142) and the operand split of the similarity product in one

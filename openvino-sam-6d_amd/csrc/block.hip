@@ -1236,6 +1236,139 @@ extern "C" int sam6d_linear_norm_split(const float* x, const void* wimage, const
   SAM6D_LAUNCH_CHECK("linear_norm_split");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// y = x W^T + b for a few thousand 256-channel token rows (the sparse-token projections: in_proj / out_proj of the coarse stage,
+// [proj_k; proj_v] of the dense layers' memory tokens -- PEM/model/coarse_point_matching.py:35-38, 61; PEM/model/transformer.py:556-558):
+// 197 workgroups of 64 rows on the panel machinery of token_block_kernel (four computing + four loader waves, two panels per ring
+// slot) instead of the generic GEMM's 64 x 64 tiles, whose ~1600 single-k-chunk workgroups are launch-latency-bound at this size.
+// Rows may be strided per cloud on both sides (row R = cloud R / rpb, token R % rpb): the bg slot of a token buffer is skipped in place.
+struct RlArgs {
+  const float* x;
+  const unsigned char* wimg;  // sam6d_pack_panels(W, 32 NP rows, k0 = 0, ksteps = 8): NP panels
+  const float* bias;          // (32 NP) or null
+  float* out;
+  long M;
+  int rpb;                    // rows per cloud
+  long x_bs, x_r0, o_bs, o_r0;  // input / output: rows between two clouds, first row of a cloud
+  float inv_w;
+  int half;
+};
+
+template <int NP>
+__global__ __launch_bounds__(512, 1) void rows_linear_kernel(RlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const unsigned pan_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  constexpr int SLOT = 2 * TB_PANEL_BYTES, NSTEP = NP / 2;
+  static_assert(NP % 2 == 0, "two panels per step");
+  if (wave >= 4) {  // loader waves
+    auto dma_step = [&](int T) {
+      const unsigned char* src = a.wimg + (size_t)T * SLOT;
+      unsigned char* dst = lds + (T & 1) * SLOT;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int pc = (wave - 4) + 4 * k;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)pc * 1024 + lane * 16),
+                                         (void __attribute__((address_space(3)))*)(dst + pc * 1024), 16, 0, 0);
+      }
+    };
+    dma_step(0);
+#pragma unroll
+    for (int T = 0; T < NSTEP; ++T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (T + 1 < NSTEP) dma_step(T + 1);
+    }
+    return;
+  }
+  const long r0 = (long)blockIdx.x * 64 + wave * 16 + fr;
+  const bool valid = r0 < a.M;
+  const long R = valid ? r0 : a.M - 1;
+  const long cb = R / a.rpb, cr = R - cb * a.rpb;
+  half8 xh[8], xl[8];
+  float sx;
+  {
+    const float* src = a.x + (size_t)(cb * a.x_bs + a.x_r0 + cr) * 256;
+    float4 va[8], vb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      va[s] = *reinterpret_cast<const float4*>(src + 32 * s + 4 * fg);
+      vb[s] = *reinterpret_cast<const float4*>(src + 32 * s + 16 + 4 * fg);
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(va[s].x), fabsf(va[s].y)), fmaxf(fabsf(va[s].z), fabsf(va[s].w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(vb[s].x), fabsf(vb[s].y)), fmaxf(fabsf(vb[s].z), fabsf(vb[s].w))));
+    }
+    sx = pow2_scale_for(tok_max(m));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float e[8] = {va[s].x, va[s].y, va[s].z, va[s].w, vb[s].x, vb[s].y, vb[s].z, vb[s].w};
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        unsigned hi, lo;
+        sam6d_split2_f16(e[u] * sx, e[u + 1] * sx, hi, lo);
+        const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
+        const _Float16 __attribute__((ext_vector_type(2))) l2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), lo);
+        xh[s][u] = h2[0];
+        xh[s][u + 1] = h2[1];
+        xl[s][u] = l2[0];
+        xl[s][u + 1] = l2[1];
+      }
+    }
+  }
+  const bool half = a.half != 0;
+  const float inv = a.inv_w * (1.0f / sx);
+  float* orow = a.out + (size_t)(cb * a.o_bs + a.o_r0 + cr) * (32 * NP);
+  tb_static_for<0, NP>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if constexpr ((j & 1) == 0) __syncthreads();  // step j / 2 has landed (loader waves) and is published
+    const unsigned p = pan_lds + ((j >> 1) & 1) * SLOT + (j & 1) * TB_PANEL_BYTES;
+    f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    tb_mma<8>(c0, c1, p, xh, xl, fr, fg, half);
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (a.bias) {
+      b0 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 4 * fg);
+      b1 = *reinterpret_cast<const float4*>(a.bias + 32 * j + 16 + 4 * fg);
+    }
+    if (valid) {
+      *reinterpret_cast<float4*>(orow + 32 * j + 4 * fg) = make_float4(c0[0] * inv + b0.x, c0[1] * inv + b0.y, c0[2] * inv + b0.z, c0[3] * inv + b0.w);
+      *reinterpret_cast<float4*>(orow + 32 * j + 16 + 4 * fg) = make_float4(c1[0] * inv + b1.x, c1[1] * inv + b1.y, c1[2] * inv + b1.z, c1[3] * inv + b1.w);
+    }
+  });
+}
+
+extern "C" int sam6d_rows_linear(const float* x, const void* wimage, int npanels, const float* bias, float inv_w_scale, float* out,
+                                 long M, int rows_per_cloud, long x_cloud_rows, long x_row0, long out_cloud_rows, long out_row0,
+                                 void* stream) {
+  SAM6D_REQUIRE(x && wimage && out && M >= 0 && inv_w_scale > 0.f, "rows_linear: bad arguments");
+  SAM6D_REQUIRE(npanels == 8 || npanels == 16, "rows_linear: built for 256 or 512 output channels (8 or 16 panels), got %d panels", npanels);
+  SAM6D_REQUIRE(rows_per_cloud > 0 && x_cloud_rows >= rows_per_cloud && out_cloud_rows >= rows_per_cloud && x_row0 >= 0 && out_row0 >= 0,
+                "rows_linear: bad row mapping");
+  SAM6D_REQUIRE(((((size_t)x) | ((size_t)wimage) | ((size_t)bias) | ((size_t)out)) & 15) == 0, "rows_linear: pointers must be 16-byte aligned");
+  if (M == 0) return 0;
+  static unsigned long long done = 0;
+  if (sam6d_first_use_on_device(&done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)rows_linear_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TB_PANEL_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)rows_linear_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TB_PANEL_BYTES);
+    if (e != hipSuccess) {
+      sam6d_set_error("rows_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&done);
+  }
+  RlArgs a{x, (const unsigned char*)wimage, bias, out, M, rows_per_cloud, x_cloud_rows, x_row0, out_cloud_rows, out_row0, inv_w_scale,
+           sam6d_half_for(1)};
+  const dim3 g((unsigned)((M + 63) / 64));
+  if (npanels == 8)
+    hipLaunchKernelGGL(rows_linear_kernel<8>, g, dim3(512), 4 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(rows_linear_kernel<16>, g, dim3(512), 4 * TB_PANEL_BYTES, (hipStream_t)stream, a);
+  SAM6D_LAUNCH_CHECK("rows_linear");
+}
+
 #define TB_LDS_BYTES(NBUF) ((NBUF) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 #define TB_LDS_BYTES2(NBUF, PSTEP) ((NBUF) * (PSTEP) * TB_PANEL_BYTES + (TC_N + 256) * 4)
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "sam6d_fine_match_workspace_bytes_n": [c_i, c_i],
     "sam6d_fine_match": [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_fine_match_split": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p],
+    "sam6d_rows_linear": [c_p, c_p, c_i, c_p, c_f, c_p, c_l, c_i, c_l, c_l, c_l, c_l, c_p],
     "sam6d_linear_norm_split": [c_p, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "sam6d_cross_attention": [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],
     "sam6d_cross_attention_kv": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p],

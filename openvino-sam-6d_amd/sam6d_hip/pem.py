@@ -26,7 +26,7 @@ def _s():
 class _Flags:
     """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
     ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn", "fused_out")
+    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn", "fused_out", "rows_linear")
 
     def __init__(self):
         env = os.environ.get
@@ -40,6 +40,7 @@ class _Flags:
         self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
         self.self_attn = env("SAM6D_SELF_ATTN", "1") == "1"  # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
         self.fused_out = self.fused_block and env("SAM6D_FUSED_OUT", "1") == "1"  # fine out_proj + normalize + operand split in one pass
+        self.rows_linear = self.fused_block and env("SAM6D_ROWS_LINEAR", "1") == "1"  # sparse-token projections on the panel kernel
         self.rpe_products = int(env("SAM6D_RPE_PRODUCTS", "0"))  # 0: what the weight set allows (geo_cheb_a_packed); 3: always three
 
 
@@ -91,11 +92,26 @@ def _empty(shape, like, dtype=torch.float32):
 
 # --------------------------------------------------------------------------------------------- weight packing
 class Linear:
-    __slots__ = ("w", "b", "_w16")
+    __slots__ = ("w", "b", "_w16", "_pimg")
 
     def __init__(self, w, b):
         self.w, self.b = w.contiguous(), (b.contiguous() if b is not None else None)
         self._w16 = None
+        self._pimg = None
+
+    def pimg(self):
+        """(image, 1 / scale, panels): the weight (256 or 512 rows x K = 256) as the 32-row panel image of csrc/block.hip's
+        rows_linear_kernel (sam6d_pack_panels), or None for another shape."""
+        if self._pimg is None:
+            N, K = self.w.shape
+            if K != C or N not in (C, 2 * C):
+                self._pimg = False
+            else:
+                sc = _pow2_scale(self.w.abs().max())
+                img = torch.zeros((N // 32) * 32768, dtype=torch.uint8, device=self.w.device)
+                _lib.call("sam6d_pack_panels", _p(self.w), K, N, 0, 8, float(sc), img.data_ptr(), _s())
+                self._pimg = (img, 1.0 / sc, N // 32)
+        return self._pimg or None
 
     def w16(self):
         """(hi, lo, scale): the weight cut into fp16 halves once (sam6d_split_f16) for sam6d_gemm_nt_w16; scale = the power of
@@ -344,14 +360,31 @@ def gemm(A, W, bias, out, M, N, K, lda, ldw, ldc, *, a_off=0, w_off=0, c_off=0, 
         launch()
 
 
-def linear(x2d, lin, *, act=0, residual=None, out=None):
-    """x2d (M,K) contiguous -> (M,N) = act(x W^T + b) (+ residual)."""
+def linear(x2d, lin, *, act=0, residual=None, out=None, cloud_rows=0):
+    """x2d (M,K) contiguous -> (M,N) = act(x W^T + b) (+ residual).  cloud_rows: tokens per cloud when the rows are the sparse tokens of
+    whole clouds (<= 512 each): the projection then runs on the panel kernel."""
     M, K = x2d.shape
     N = lin.w.shape[0]
     if out is None:
         out = _empty((M, N), x2d)
+    if cloud_rows and act == 0 and residual is None and K == C and M % cloud_rows == 0 and \
+            rows_linear(x2d, lin, out, M, cloud_rows, cloud_rows, 0, cloud_rows, 0):
+        return out
     gemm(x2d, lin.w, lin.b, out, M, N, K, K, K, N, residual=residual, ldr=N, act=act, w16=lin.w16())
     return out
+
+
+def rows_linear(x, lin, out, M, rpb, x_bs, x_r0, o_bs, o_r0):
+    """out rows = x rows @ lin.w^T + lin.b for M = clouds * rpb token rows of 256 channels; row R = (cloud R // rpb, token R % rpb) sits at
+    row cloud * x_bs + x_r0 + token of x and cloud * o_bs + o_r0 + token of out (rows of 256 / lin.w.shape[0] floats).  False when the
+    panel kernel does not serve this Linear / size (the caller then launches the GEMM)."""
+    if not _flags().rows_linear or M <= 0 or rpb > 512:  # (by tokens per cloud, never by batch size: a shard must take the same path as the whole batch)
+        return False
+    pi = lin.pimg()
+    if pi is None:
+        return False
+    _lib.call("sam6d_rows_linear", _p(x), pi[0].data_ptr(), pi[2], _p(lin.b), float(pi[1]), _p(out), M, rpb, x_bs, x_r0, o_bs, o_r0, _s())
+    return True
 
 
 def layernorm(x2d, gb, out=None):
@@ -845,7 +878,8 @@ def linear_transformer_layer(D, S, L):
     if not (I * J * 128 > 64 * 64 * (I + J)):
         raise RuntimeError("linear attention: only the kv contraction order is implemented (transformer.py:569-572)")
     kv = _empty((Bp, J, 2 * C), D)
-    gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C, w16=L["kv"].w16())
+    if not rows_linear(S, L["kv"], kv, Bp * J, J, J + 1, 1, J, 0):
+        gemm(S, L["kv"].w, L["kv"].b, kv, J, 2 * C, C, C, C, 2 * C, a_off=C, batch=Bp, sA=(J + 1) * C, sC=J * 2 * C, w16=L["kv"].w16())
     ksum = _empty((Bp, H, 64), D)
     if _fused_block() and "tbd" in L:
         # the whole layer on the dense tokens (rows 1 .. I-1 of every cloud) in one launch; row 0 (the bg slot) is written by the caller
@@ -930,7 +964,7 @@ def positional_encoding_add(pts, W, dst, dst_off, dst_sb, r1=0.1, r2=0.2, ns1=32
 def feature_similarity(F, B, n, out_proj, temp):
     """F (2B,n,256) -> atten (B,n,n) = normalize(out_proj(F0)) @ normalize(out_proj(F1))^T / temp
     (PEM/utils/model_utils.py:131-153)."""
-    f = linear(F.reshape(2 * B * n, C), out_proj)
+    f = linear(F.reshape(2 * B * n, C), out_proj, cloud_rows=n)
     _lib.call("sam6d_l2norm256", _p(f), _p(f), 2 * B * n, C, C, _s())
     att = _empty((B, n, n), F)
     gemm(f, f, None, att, n, n, C, C, C, n, w_off=B * n * C, batch=B, sA=n * C, sW=n * C, sC=n * n, divisor=temp)
@@ -1126,7 +1160,8 @@ def _tokens_with_bg(x, lin, bg, extra=None):
         return T
     Bp, N, K = x.shape
     T = _empty((Bp, N + 1, C), x)
-    gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+    if not (K == C and rows_linear(x, lin, T, Bp * N, N, N, 0, N + 1, 1)):
+        gemm(x, lin.w, lin.b, T, N, C, K, K, K, C, c_off=C, batch=Bp, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
     _lib.call("sam6d_put_rows", _p(bg), 0, C, _p(T), (N + 1) * C, C, Bp, 1, C, _s())
     return T
 
@@ -1237,6 +1272,7 @@ def _ensure_w16(W):
     def walk(o):
         if isinstance(o, Linear):
             o.w16()
+            o.pimg()
         elif isinstance(o, dict):
             for v in o.values():
                 walk(v)

@@ -349,6 +349,27 @@ def test_linear_norm_split_vs_fp64(dev, M, xs):
     assert float(fl.float().abs().max()) <= float(fh.float().abs().max()) * 2.0 ** -10 + 1e-3
 
 
+@pytest.mark.parametrize("clouds,rpb,N,xs", [(4, 196, 512, 1.0), (3, 197, 256, 1.0), (1, 1, 256, 1.0), (2, 130, 512, 3e3), (64, 196, 256, 1e-3)])
+def test_rows_linear_vs_fp64(dev, clouds, rpb, N, xs):
+    """sam6d_rows_linear: y = x W^T + b for the token rows of a buffer with a skipped bg slot on the input side and on the output side
+    (the sparse-token projections; PEM/model/coarse_point_matching.py:35-38, PEM/model/transformer.py:556-558) against float64."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(clouds * 1000 + rpb + N)
+    w = (torch.rand(N, 256, generator=gen) * 2 - 1) / 16
+    b = (torch.rand(N, generator=gen) * 2 - 1) * xs
+    x = torch.randn(clouds, rpb + 1, 256, generator=gen) * xs   # row 0 of every cloud: the bg slot, skipped
+    x[:, 0] = float("nan")
+    L = pem.Linear(w.to(dev), b.to(dev))
+    out = torch.full((clouds, rpb + 2, N), 7.0, device=dev)     # rows 0 and 1 of every cloud stay untouched
+    ok = pem.rows_linear(x.to(dev).contiguous(), L, out, clouds * rpb, rpb, rpb + 1, 1, rpb + 2, 2)
+    assert ok
+    got = out.cpu().double()
+    want = x[:, 1:].double() @ w.double().t() + b.double()
+    assert torch.all(got[:, :2] == 7.0)
+    err = float((got[:, 2:] - want).abs().max())
+    assert torch.isfinite(got).all() and err < 2e-6 * max(1.0, float(want.abs().max())), "rows_linear vs fp64: %.3e" % err
+
+
 def test_geometric_transformer_writes_stacked_halves(dev):
     """The two sequential cross layers write their halves of the stacked (2B, n, 256) result in place: equal to the layers called one
     by one (PEM/model/transformer.py:517-524: feats1 attends to the already-updated feats0)."""
