@@ -23,6 +23,22 @@ x2 = S.reshape(-1, 256)
 hid = torch.randn_like(x2)
 
 
+def _xattn():
+    L = T["cross"]
+    out = torch.empty(B, 197, 256, device=dev)
+    _lib.call("sam6d_cross_attention_kv", pem._p(S[:B]), pem._p(S[B:]), L["xq"]["img"].data_ptr(), pem._p(L["q"].b), float(L["xq"]["inv"]),
+              L["xkv"]["img"].data_ptr(), pem._p(L["kv"].b), float(L["xkv"]["inv"]), pem._p(out), B, 197, 197, pem._s())
+
+
+_QKV = torch.randn(2 * B * 197, 768, device=dev)
+_G = torch.randn(2 * B * 197, 4, 200, device=dev)
+
+
+def _sattn():
+    out = torch.empty(2 * B * 197, 256, device=dev)
+    _lib.call("sam6d_rpe_self_attention", pem._p(_QKV), pem._p(_G), pem._p(out), 2 * B, 197, 200, pem._s())
+
+
 def _front():
     L = T["self"]
     fr = L["front"]
@@ -86,6 +102,8 @@ ops = {
     "token_block_12608": lambda: pem._post_attention(hid, x2, T["self"]),
     "token_block_6304": lambda: pem._post_attention(hid[:6304], x2[:6304], T["cross"]),
     "self_layer": lambda: pem.rpe_self_layer(S, G, T["self"]),
+    "xattn_only": lambda: _xattn(),
+    "sattn_only": lambda: _sattn(),
     "cross_layer": lambda: pem.cross_layer(S[:B], S[B:], T["cross"]),
     "geo_transformer_block": lambda: pem.geometric_transformer(S, G, T),
     "dense_layer": lambda: pem.linear_transformer_layer(DD, S, FT),
