@@ -16,6 +16,7 @@
 //     out^T (64 x tok) = v_h^T (64 x 224) . P^T         7 k-steps
 // fp16 x3 split products with power-of-two operand scales (per token row for x, q, P; per image for Wq, k, v): range-safe, ~1e-6.
 #include "common.h"
+#include <type_traits>
 #include "../../include/sam6d_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -514,6 +515,15 @@ extern "C" int sam6d_cross_attention_kv(const float* x, const float* mem, const 
 // the accumulator holds keys 16 i + 4 g + r of the lane's own query), softmax, out^T = v_h^T P^T (7 k-steps).
 // Before: a 4096-workgroup batched GEMM for q.k^T (35 us), the softmax inside the score kernel, and a second batched GEMM for P.v
 // (22 us) -- both launch-latency-bound at 197 x 197 x 64 per (cloud, head).
+#ifdef SA_STAMP  // diagnostic build only (scratch/sa_stamps.py): per-wave s_memtime stamps of sattn_kernel; no output depends on them
+__device__ unsigned long long sa_stamps[256 * 8 * 16];
+extern "C" int sam6d_sattn_debug_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sa_stamps), sizeof(sa_stamps));
+}
+#define SA_ST(i) st[i] = __builtin_amdgcn_s_memtime()
+#else
+#define SA_ST(i)
+#endif
 struct SaArgs {
   const float* qkv;   // (B n, 768): q | k | v
   const float* G;     // (B n, 4, ldp) geometric score term (raw, not yet / 8)
@@ -521,6 +531,38 @@ struct SaArgs {
   int n, ldp;
   int half;
 };
+
+// S^T tiles 0 .. NT-1 (16 keys each, K = 64 = 2 k-steps) as ONE stream of 2 NT steps through a fragment ring: the reads of step
+// S + XA_FD go out before the MFMAs of step S.  (xa_mma per tile issues its reads only after the previous tile's MFMAs: stamps put
+// the 13 tiles of a group at ~7 000 cycles for 1 250 cycles of MFMA issue.)
+#define XA_FDR 4  // ring depth of the score-tile stream
+template <int NT, int S>
+__device__ __forceinline__ void xa_rows_step(f32x4* acc, unsigned kb, int fr, int fg, const half8* __restrict__ xh,
+                                             const half8* __restrict__ xl, xa_u32x4 (&fh)[XA_FDR + 1], xa_u32x4 (&fl)[XA_FDR + 1], bool half) {
+  auto issue = [&](int st) {
+    const int row = 16 * (st >> 1) + fr, ks = st & 1;
+    const int ch = 4 * ks + fg, cl = 8 + 4 * ks + fg;
+    const unsigned rb = kb + (unsigned)row * 256;
+    fh[st % (XA_FDR + 1)] = xa_lds128(rb + ((((ch & ~15) | ((ch ^ row) & 15))) << 4));
+    fl[st % (XA_FDR + 1)] = xa_lds128(rb + ((((cl & ~15) | ((cl ^ row) & 15))) << 4));
+  };
+  if constexpr (S == 0) {
+#pragma unroll
+    for (int st = 0; st < XA_FDR && st < 2 * NT; ++st) issue(st);
+  }
+  if constexpr (S + XA_FDR < 2 * NT) issue(S + XA_FDR);
+  constexpr int newer = (2 * NT - 1 - S) < XA_FDR ? (2 * NT - 1 - S) : XA_FDR;
+  constexpr int cur = S % (XA_FDR + 1);
+  xa_wait<2 * newer>(fh[cur], fl[cur]);
+  const half8 ah = __builtin_bit_cast(half8, fh[cur]), al = __builtin_bit_cast(half8, fl[cur]);
+  f32x4& c = acc[S >> 1];
+  if (!half) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[S & 1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[S & 1], c, 0, 0, 0);
+  }
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[S & 1], c, 0, 0, 0);
+  if constexpr (S + 1 < 2 * NT) xa_rows_step<NT, S + 1>(acc, kb, fr, fg, xh, xl, fh, fl, half);
+}
 
 __global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -531,22 +573,28 @@ __global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fg = lane >> 4;
   const int n = a.n, m = a.n;
   const bool half = a.half != 0;
-  constexpr int XA_EPT = (XA_MAXKEY * 64) / (XA_WAVES * 64);  // 26
-  const float* kb = a.qkv + (size_t)b * n * 768 + 256 + 64 * h;
-  const float* vb = kb + 256;
-  float kreg[XA_EPT], vreg[XA_EPT];
-#pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {  // one burst of independent loads: element e = t + 512 i is (key e >> 6, channel e & 63)
-    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
-    const bool ok = j < m;
-    kreg[i] = ok ? kb[(size_t)j * 768 + d] : 0.f;
-    vreg[i] = ok ? vb[(size_t)j * 768 + d] : 0.f;
-  }
-  // the query rows of this wave's first group are requested now as well
   const int ngroups = (n + 15) >> 4;
+#ifdef SA_STAMP
+  unsigned long long st[16];
+  for (int i = 0; i < 16; ++i) st[i] = 0;
+#endif
+  SA_ST(0);
+  // ---- everything this wave will read from global memory is requested up front (stamps: the score-term tiles alone, requested where
+  // they are used, cost each group ~10 000 cycles of exposed latency, and 52 scalar element loads per thread 10 000 cycles of issue):
+  // the score-term tiles and query rows of the first token group (the second group's during the first one's softmax), the head's keys as float4 (key j, channels 4 c .. 4 c + 3), its values
+  // as 4 scalars (channel d, keys 4 q .. 4 q + 3: the transposed image wants consecutive keys of one channel)
+  float4 gt[XA_NT];  // the score-term tiles of the group at hand (group 1's are requested while group 0's softmax runs)
   float4 qa[2][2], qb[2][2];
+  // G tiles of the lane's query: keys 16 i + 4 g .. + 3 (a row of ldp = 4 ceil(n / 4) floats, so a started float4 stays inside it)
+  auto load_g = [&](int gi) {
+    const int grp = wave + XA_WAVES * gi;
+    const int tok = min(grp * 16 + fr, n - 1);
+    const float* grow = a.G + (((size_t)b * n + tok) * 4 + h) * a.ldp + 4 * fg;
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
+    for (int i = 0; i < XA_NT; ++i)
+      gt[i] = (grp < ngroups && 16 * i + 4 * fg < m) ? *reinterpret_cast<const float4*>(grow + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto load_q = [&](int gi) {
     const int grp = wave + XA_WAVES * gi;
     const int tok = min(grp * 16 + fr, n - 1);
     const float* src = a.qkv + ((size_t)b * n + tok) * 768 + 64 * h;
@@ -555,60 +603,90 @@ __global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
       qa[gi][s2] = *reinterpret_cast<const float4*>(src + 32 * s2 + 4 * fg);
       qb[gi][s2] = *reinterpret_cast<const float4*>(src + 32 * s2 + 16 + 4 * fg);
     }
+  };
+  constexpr int XA_KT = (XA_MAXKEY * 16 + XA_WAVES * 64 - 1) / (XA_WAVES * 64);        // 7 float4 of k per thread
+  constexpr int XA_VT = ((XA_MAXKEY / 4) * 64 + XA_WAVES * 64 - 1) / (XA_WAVES * 64);  // 7 key quads of v per thread
+  const float* kb = a.qkv + (size_t)b * n * 768 + 256 + 64 * h;
+  const float* vb = kb + 256;
+  float4 kreg[XA_KT];
+  float vreg[XA_VT][4];
+#pragma unroll
+  for (int i = 0; i < XA_KT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 4, c4 = e & 15;
+    kreg[i] = (j < m) ? *reinterpret_cast<const float4*>(kb + (size_t)j * 768 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // the v^T image is cleared first: its key slots >= m are multiplied by zero probabilities only, but must not hold NaN patterns
+#pragma unroll
+  for (int i = 0; i < XA_VT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, d = e & 63, jq = e >> 6;  // a wave reads 64 consecutive channels of one key
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 4 * jq + r;
+      vreg[i][r] = (j < m) ? vb[(size_t)j * 768 + d] : 0.f;
+    }
+  }
+  // (behind the key / value loads: the vector-memory counter retires in order, and the images are built first)
+  load_g(0);
+  load_q(0);
+  // the v^T image is cleared first: its key slots >= 208 are multiplied by zero probabilities only, but must not hold NaN patterns
   for (int i = t; i < XA_WQ_BYTES / 16; i += XA_WAVES * 64) reinterpret_cast<uint4*>(regA)[i] = make_uint4(0u, 0u, 0u, 0u);
   float mk = 0.f, mv = 0.f;
 #pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    mk = fmaxf(mk, fabsf(kreg[i]));
-    mv = fmaxf(mv, fabsf(vreg[i]));
-  }
+  for (int i = 0; i < XA_KT; ++i) mk = fmaxf(mk, fmaxf(fmaxf(fabsf(kreg[i].x), fabsf(kreg[i].y)), fmaxf(fabsf(kreg[i].z), fabsf(kreg[i].w))));
+#pragma unroll
+  for (int i = 0; i < XA_VT; ++i) mv = fmaxf(mv, fmaxf(fmaxf(fabsf(vreg[i][0]), fabsf(vreg[i][1])), fmaxf(fabsf(vreg[i][2]), fabsf(vreg[i][3]))));
   mk = wave_max_dpp(mk);
   mv = wave_max_dpp(mv);
+  SA_ST(1);
   if (lane == 0) { red[wave] = mk; red[8 + wave] = mv; }
   __syncthreads();
+  SA_ST(2);
   float sk = 0.f, sv = 0.f;
 #pragma unroll
   for (int w = 0; w < XA_WAVES; ++w) { sk = fmaxf(sk, red[w]); sv = fmaxf(sv, red[8 + w]); }
   sk = xa_pow2_scale(sk);
   sv = xa_pow2_scale(sv);
+  typedef unsigned sa_u2 __attribute__((ext_vector_type(2)));
+  // k_h image: channels 4 c .. 4 c + 3 of key j are four consecutive slots (8 bytes) of its row; every (key < 208, channel) slot is
+  // written (zeros beyond m)
 #pragma unroll
-  for (int i = 0; i < XA_EPT; ++i) {
-    const int e = t + XA_WAVES * 64 * i, j = e >> 6, d = e & 63;
-    {  // k_h image: every (key < 208, channel) slot is written (zeros beyond m)
-      _Float16 hi, lo;
-      sam6d_split_f16(kreg[i] * sk, hi, lo);
-      const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);
-      _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
-      const int ch = p >> 3, cl = 8 + (p >> 3);
-      row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
-      row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
-    }
-    {  // v_h^T image: row d, K = key
-      _Float16 hi, lo;
-      sam6d_split_f16(vreg[i] * sv, hi, lo);
-      const int p = 32 * (j >> 5) + xa_channel_slot(j & 31);
-      _Float16* row = reinterpret_cast<_Float16*>(regA + (size_t)d * 1024);
-      const int ch = p >> 3, cl = 32 + (p >> 3);
-      row[((((ch & ~15) | ((ch ^ d) & 15))) << 3) + (p & 7)] = hi;
-      row[((((cl & ~15) | ((cl ^ d) & 15))) << 3) + (p & 7)] = lo;
+  for (int i = 0; i < XA_KT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, j = e >> 4, c4 = e & 15;
+    if (j < XA_MAXKEY) {
+      unsigned h01, l01, h23, l23;
+      sam6d_split2_f16(kreg[i].x * sk, kreg[i].y * sk, h01, l01);
+      sam6d_split2_f16(kreg[i].z * sk, kreg[i].w * sk, h23, l23);
+      const int ch = 4 * (c4 >> 3) + (c4 & 3), cl = 8 + ch, off = ((c4 >> 2) & 1) * 8;  // slot 32 (d >> 5) + 8 ((d >> 2) & 3) + 4 ((d >> 4) & 1) + (d & 3)
+      unsigned char* row = kimg + (size_t)j * 256;
+      *reinterpret_cast<sa_u2*>(row + ((ch ^ (j & 15)) << 4) + off) = sa_u2{h01, h23};
+      *reinterpret_cast<sa_u2*>(row + ((cl ^ (j & 15)) << 4) + off) = sa_u2{l01, l23};
     }
   }
+  // v_h^T image: row d, K = key; keys 4 q .. 4 q + 3 are four consecutive slots
+#pragma unroll
+  for (int i = 0; i < XA_VT; ++i) {
+    const int e = t + XA_WAVES * 64 * i, d = e & 63, jq = e >> 6;
+    if (4 * jq < XA_MAXKEY) {
+      unsigned h01, l01, h23, l23;
+      sam6d_split2_f16(vreg[i][0] * sv, vreg[i][1] * sv, h01, l01);
+      sam6d_split2_f16(vreg[i][2] * sv, vreg[i][3] * sv, h23, l23);
+      const int j0 = 4 * jq, p = 32 * (j0 >> 5) + xa_channel_slot(j0 & 31);
+      const int ch = p >> 3, cl = 32 + (p >> 3), off = (p & 7) * 2;
+      unsigned char* row = regA + (size_t)d * 1024;
+      *reinterpret_cast<sa_u2*>(row + ((((ch & ~15) | ((ch ^ d) & 15))) << 4) + off) = sa_u2{h01, h23};
+      *reinterpret_cast<sa_u2*>(row + ((((cl & ~15) | ((cl ^ d) & 15))) << 4) + off) = sa_u2{l01, l23};
+    }
+  }
+  SA_ST(3);
   __syncthreads();
+  SA_ST(4);
 
   const float inv_k = 1.0f / sk, inv_v = (1.0f / sv) * (1.0f / 16384.0f);
-#pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
+  const unsigned kimg_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)kimg;
+  auto group = [&](auto GI) {
+    constexpr int gi = decltype(GI)::value;
     const int grp = wave + XA_WAVES * gi;
     if (grp < ngroups) {  // (wave-uniform)
       const int tok = min(grp * 16 + fr, n - 1);
-      // G tiles of the lane's query: keys 16 i + 4 g .. + 3 (a row of ldp = 4 ceil(n / 4) floats, so a started float4 stays inside it)
-      const float* grow = a.G + (((size_t)b * n + tok) * 4 + h) * a.ldp + 4 * fg;
-      float4 gt[XA_NT];
-#pragma unroll
-      for (int i = 0; i < XA_NT; ++i)
-        gt[i] = 16 * i + 4 * fg < m ? *reinterpret_cast<const float4*>(grow + 16 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
       // q / 8 (the softmax scale 1 / sqrt(64): a power of two) as split B fragments
       half8 qh[2], ql[2];
       float qm = 0.f;
@@ -632,10 +710,13 @@ __global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
       }
       f32x4 s[XA_NT];
 #pragma unroll
-      for (int i = 0; i < XA_NT; ++i) {
-        s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        xa_mma<256, 8, 2>(s[i], kimg, 16 * i, qh, ql, fr, fg, half);
+      for (int i = 0; i < XA_NT; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      SA_ST(5 + 5 * gi);
+      {
+        xa_u32x4 fh[XA_FDR + 1], fl[XA_FDR + 1];
+        xa_rows_step<XA_NT, 0>(s, kimg_lds, fr, fg, qh, ql, fh, fl, half);
       }
+      SA_ST(6 + 5 * gi);
       const float inv = inv_k * (1.0f / sq);
       float mx = -INFINITY;
 #pragma unroll
@@ -670,20 +751,34 @@ __global__ __launch_bounds__(XA_WAVES * 64) void sattn_kernel(SaArgs a) {
           ph[i >> 1][4 * (i & 1) + r] = hi;
           pl[i >> 1][4 * (i & 1) + r] = lo;
         }
+      if (gi == 0) {  // the next group's inputs: in flight under this group's P.v and store and the next group's score tiles
+        load_g(1);      // (requested earlier, beside the logits and the probability halves, they do not fit the register file)
+        load_q(1);
+      }
       f32x4 o[4];
+      SA_ST(7 + 5 * gi);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         xa_mma<1024, 32, 7>(o[i], regA, 16 * i, ph, pl, fr, fg, half);
       }
+      SA_ST(8 + 5 * gi);
       if (grp * 16 + fr < n) {
         float* dst = a.out + ((size_t)b * n + tok) * 256 + 64 * h;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           *reinterpret_cast<float4*>(dst + 16 * i + 4 * fg) = make_float4(o[i][0] * inv_v, o[i][1] * inv_v, o[i][2] * inv_v, o[i][3] * inv_v);
       }
+      SA_ST(9 + 5 * gi);
     }
-  }
+  };
+  group(std::integral_constant<int, 0>{});
+  group(std::integral_constant<int, 1>{});
+#ifdef SA_STAMP
+  st[15] = __builtin_amdgcn_s_memtime();
+  if (lane == 0 && blockIdx.y * 4 + blockIdx.x < 256)
+    for (int i = 0; i < 16; ++i) sa_stamps[((blockIdx.y * 4 + blockIdx.x) * 8 + wave) * 16 + i] = st[i];
+#endif
 }
 
 extern "C" int sam6d_rpe_self_attention(const float* qkv, const float* G, float* hidden, int B, int n, int ldp, void* stream) {
