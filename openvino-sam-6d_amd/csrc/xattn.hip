@@ -16,6 +16,7 @@
 //     out^T (64 x tok) = v_h^T (64 x 224) . P^T         7 k-steps
 // fp16 x3 split products with power-of-two operand scales (per token row for x, q, P; per image for Wq, k, v): range-safe, ~1e-6.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "../../include/sam6d_hip.h"
 
@@ -288,14 +289,18 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
 
   // ---- phase 1: q^T for this wave's token groups (kept as split B fragments: 2 k-steps each)
   const int ngroups = (n + 15) >> 4;
+  // gridDim.z = 2: the query groups are dealt to two workgroups per (cloud, head) -- each projects all keys / values of the head, but
+  // runs one query group per wave instead of two (a cross layer of 32 clouds is 128 workgroups: half of the CUs idle otherwise)
+  const int g_first = gridDim.z == 2 ? (ngroups + 1) >> 1 : ngroups;
+  const int g_off = blockIdx.z ? g_first : 0, g_cnt = blockIdx.z ? ngroups - g_first : g_first;
   half8 qh[2][2], ql[2][2];
   float sq[2] = {1.f, 1.f};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // Wq image landed, k image complete
 #pragma unroll
   for (int gi = 0; gi < 2; ++gi) {
-    const int grp = wave + XA_WAVES * gi;
-    if (grp < ngroups) {  // (wave-uniform)
+    const int grp = g_off + wave + XA_WAVES * gi;
+    if (wave + XA_WAVES * gi < g_cnt) {  // (wave-uniform)
       const int tok = min(grp * 16 + fr, n - 1);
       const float* src = a.x + ((size_t)b * n + tok) * 256;
       half8 xh[8], xl[8];
@@ -400,8 +405,8 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   const float inv_k = 1.0f / sk, inv_v = (1.0f / sv) * (1.0f / 16384.0f);
 #pragma unroll
   for (int gi = 0; gi < 2; ++gi) {
-    const int grp = wave + XA_WAVES * gi;
-    if (grp < ngroups) {
+    const int grp = g_off + wave + XA_WAVES * gi;
+    if (wave + XA_WAVES * gi < g_cnt) {
       f32x4 s[XA_NT];
 #pragma unroll
       for (int i = 0; i < XA_NT; ++i) {
@@ -458,9 +463,28 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
   }
 }
 
+static int xa_cu_count[SAM6D_MAX_DEVICES];
+// query split of a launch: two workgroups per (cloud, head) while they all fit the chip at once (the results do not depend on it)
+static int xa_qsplit(int B, int n) {
+  static int allow = -1;  // SAM6D_XATTN_QSPLIT=0: always one workgroup per (cloud, head) (A/B runs)
+  if (allow < 0) {
+    const char* e = getenv("SAM6D_XATTN_QSPLIT");
+    allow = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!allow) return 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SAM6D_MAX_DEVICES) return 1;
+  const int cu = xa_cu_count[dev];
+  return (cu > 0 && 8 * B <= cu && n > 16) ? 2 : 1;
+}
 static int xa_reserve() {
   static unsigned long long done = 0;
-  if (sam6d_first_use_on_device(&done)) {
+  int dev_ = 0;
+  if (sam6d_first_use_on_device(&done, &dev_)) {
+    if (dev_ >= 0 && dev_ < SAM6D_MAX_DEVICES) {
+      int cu = 0;
+      if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev_) == hipSuccess) xa_cu_count[dev_] = cu;
+    }
     hipError_t e = hipFuncSetAttribute((const void*)xattn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)xattn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS_KV);
     if (e != hipSuccess) {
@@ -483,7 +507,7 @@ extern "C" int sam6d_cross_attention(const float* x, const float* kv, const void
   if (B == 0) return 0;
   if (int rc = xa_reserve()) return rc;
   XaArgs a{x, kv, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2), nullptr, nullptr, 1.0f};
-  hipLaunchKernelGGL(xattn_kernel<false>, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(xattn_kernel<false>, dim3(4, B, xa_qsplit(B, n)), dim3(XA_WAVES * 64), XA_LDS, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention");
 }
 
@@ -502,7 +526,7 @@ extern "C" int sam6d_cross_attention_kv(const float* x, const float* mem, const 
   if (int rc = xa_reserve()) return rc;
   XaArgs a{x, mem, (const unsigned char*)wq_image, bq, out, n, m, inv_wq_scale, sam6d_half_for(2), (const unsigned char*)wkv_image, bkv,
            inv_wkv_scale};
-  hipLaunchKernelGGL(xattn_kernel<true>, dim3(4, B), dim3(XA_WAVES * 64), XA_LDS_KV, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(xattn_kernel<true>, dim3(4, B, xa_qsplit(B, n)), dim3(XA_WAVES * 64), XA_LDS_KV, (hipStream_t)stream, a);
   SAM6D_LAUNCH_CHECK("cross_attention_kv");
 }
 
