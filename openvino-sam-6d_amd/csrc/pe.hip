@@ -229,6 +229,21 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     qxA = pts[(long)pA * 3] + 0.00000001f; qyA = pts[(long)pA * 3 + 1] + 0.00000001f; qzA = pts[(long)pA * 3 + 2] + 0.00000001f;
   }
   if (pB < total) nbB = idx[(long)pB * S + tB * 32 + fr];
+  // layer-1 weight fragments of this lane (row = channel fr): w1a = hi halves (lanes 0-31) / lo halves (lanes 32-63) of W1[fr][0..5],
+  // w1b = hi halves in lanes 0-31, zeros above
+  typedef unsigned pe_u4 __attribute__((ext_vector_type(4)));
+  half8 w1a, w1b;
+  {
+    float wv[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) wv[f] = w1s[fr * 7 + f];
+    unsigned h01, l01, h23, l23, h45, l45;
+    sam6d_split2_f16(wv[0], wv[1], h01, l01);
+    sam6d_split2_f16(wv[2], wv[3], h23, l23);
+    sam6d_split2_f16(wv[4], wv[5], h45, l45);
+    w1a = __builtin_bit_cast(half8, fk ? pe_u4{l01, l23, l45, 0u} : pe_u4{h01, h23, h45, 0u});
+    w1b = __builtin_bit_cast(half8, fk ? pe_u4{0u, 0u, 0u, 0u} : pe_u4{h01, h23, h45, 0u});
+  }
   float mx[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0, so 0 is a neutral start for the max
   int wrow = fr, wk = 8 * fk;  // this lane's row / k offset in the weight images
   while (pA < total) {
@@ -244,16 +259,23 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
       xB = ok ? pb[nbB * 3] : 0.f; yB = ok ? pb[nbB * 3 + 1] : 0.f; zB = ok ? pb[nbB * 3 + 2] : 0.f;
       qxB = pts[(long)pB * 3] + 0.00000001f; qyB = pts[(long)pB * 3 + 1] + 0.00000001f; qzB = pts[(long)pB * 3 + 2] + 0.00000001f;
     }
-    // ---- layer 1 (transposed): D1T[ch][nb] = W1[ch][f] F[f][nb], f = 2i + fk: {x-qx, y-qy, z-qz, x, y, z}
-    const float f0 = fk ? (yA - qyA) : (xA - qxA);
-    const float f1 = fk ? xA : (zA - qzA);
-    const float f2 = fk ? zA : yA;
+    // ---- layer 1 (transposed): D1T[ch][nb] = W1[ch][f] F[f][nb], f: {x-qx, y-qy, z-qz, x, y, z}.  K = 6 leaves room for all three
+    // split products in TWO v_mfma_f32_32x32x16_f16: k slots 0..5 of the lower lane half carry w_hi . x_hi, of the upper half w_lo . x_hi
+    // (first instruction), then w_hi . x_lo in the lower half (second).  (Was three v_mfma_f32_32x32x2_f32 = 192 cycles per tile during
+    // which the SIMD's other waves cannot issue vector instructions; these are 64 cycles and overlap with them.)
     f32x16 a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 0 + fk], f0, a1, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 2 + fk], f1, a1, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[fr * 7 + 4 + fk], f2, a1, 0, 0, 0);
+    {
+      unsigned h01, l01, h23, l23, h45, l45;
+      sam6d_split2_f16(xA - qxA, yA - qyA, h01, l01);
+      sam6d_split2_f16(zA - qzA, xA, h23, l23);
+      sam6d_split2_f16(yA, zA, h45, l45);
+      const half8 bx = __builtin_bit_cast(half8, pe_u4{h01, h23, h45, 0u});
+      const half8 bl = __builtin_bit_cast(half8, fk ? pe_u4{0u, 0u, 0u, 0u} : pe_u4{l01, l23, l45, 0u});
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1a, bx, a1, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1b, bl, a1, 0, 0, 0);
+    }
     half8 h1h[2], h1l[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) pe_split8(a1, s, bn, bn + 32, wk >> 3, h1h[s], h1l[s]);
