@@ -179,7 +179,7 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     const float* __restrict__ pts, const int* __restrict__ idx, int N, int S, int total, const float* __restrict__ W1,
     const float* __restrict__ sc1, const float* __restrict__ sh1, const float* __restrict__ W2, const float* __restrict__ sc2,
     const float* __restrict__ sh2, const float* __restrict__ W3, const float* __restrict__ sc3, const float* __restrict__ sh3,
-    float* __restrict__ out, long ldo, int off) {
+    float* __restrict__ out, long ldo, int off, unsigned ndiv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
   float* w1s = reinterpret_cast<float*>(lraw);                  // [32][7] fp32
   float* bn = w1s + 32 * 7;                                     // sc1 32 | sh1 32 | sc2 64 | sh2 64 | sc3 128 | sh3 128
@@ -209,6 +209,10 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
   __syncthreads();
   const int fr = lane & 31, fk = lane >> 5;
   const int ntile = S >> 5;
+  // cloud of point p: p / N by a multiply-high with ndiv = floor(2^32 / N) + 1 (exact while p N < 2^32: checked on the host), so the
+  // prefetch code of a tile is straight-line -- the loads below are unconditional on clamped indices, the selects follow (stamps: the
+  // branchy form with its integer division cost each wave ~1 350 cycles per tile)
+  auto cloud_base = [&](int p) -> long { return (long)(ndiv ? (int)__umulhi((unsigned)p, ndiv) : p / N) * N * 3; };
   const int GW = gridDim.x * PH_WAVES;
   float s3[4], h3[4];
 #pragma unroll
@@ -223,12 +227,12 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
   int nbB = 0;
   if (pA < total) {
     const int nb = idx[(long)pA * S + tA * 32 + fr];
-    const float* pb = pts + (long)(pA / N) * N * 3;
+    const float* pb = pts + cloud_base(pA);
     const bool ok = nb >= 0 && nb < N;
     xA = ok ? pb[nb * 3] : 0.f; yA = ok ? pb[nb * 3 + 1] : 0.f; zA = ok ? pb[nb * 3 + 2] : 0.f;
     qxA = pts[(long)pA * 3] + 0.00000001f; qyA = pts[(long)pA * 3 + 1] + 0.00000001f; qzA = pts[(long)pA * 3 + 2] + 0.00000001f;
   }
-  if (pB < total) nbB = idx[(long)pB * S + tB * 32 + fr];
+  nbB = idx[(long)min(pB, total - 1) * S + tB * 32 + fr];
   // layer-1 weight fragments of this lane (row = channel fr): w1a = hi halves (lanes 0-31) / lo halves (lanes 32-63) of W1[fr][0..5],
   // w1b = hi halves in lanes 0-31, zeros above
   typedef unsigned pe_u4 __attribute__((ext_vector_type(4)));
@@ -250,14 +254,16 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     // the weight reads are loop-invariant: keep them inside the loop (hoisted, they would not fit the register file)
     asm volatile("" : "+v"(wrow), "+v"(wk));
     // ---- prefetch: indices of tile C, coordinates of tile B
-    int nbC = 0;
-    if (pC < total) nbC = idx[(long)pC * S + tC * 32 + fr];
-    float xB = 0.f, yB = 0.f, zB = 0.f, qxB = 0.f, qyB = 0.f, qzB = 0.f;
-    if (pB < total) {
-      const float* pb = pts + (long)(pB / N) * N * 3;
+    const int nbC = idx[(long)min(pC, total - 1) * S + tC * 32 + fr];  // (past the end: the last point's indices, never used)
+    float xB, yB, zB, qxB, qyB, qzB;
+    {
+      const int pBc = min(pB, total - 1);
+      const float* pb = pts + cloud_base(pBc);
       const bool ok = nbB >= 0 && nbB < N;
-      xB = ok ? pb[nbB * 3] : 0.f; yB = ok ? pb[nbB * 3 + 1] : 0.f; zB = ok ? pb[nbB * 3 + 2] : 0.f;
-      qxB = pts[(long)pB * 3] + 0.00000001f; qyB = pts[(long)pB * 3 + 1] + 0.00000001f; qzB = pts[(long)pB * 3 + 2] + 0.00000001f;
+      const int nbc = ok ? nbB : 0;
+      xB = pb[nbc * 3]; yB = pb[nbc * 3 + 1]; zB = pb[nbc * 3 + 2];
+      xB = ok ? xB : 0.f; yB = ok ? yB : 0.f; zB = ok ? zB : 0.f;
+      qxB = pts[(long)pBc * 3] + 0.00000001f; qyB = pts[(long)pBc * 3 + 1] + 0.00000001f; qzB = pts[(long)pBc * 3 + 2] + 0.00000001f;
     }
     // ---- layer 1 (transposed): D1T[ch][nb] = W1[ch][f] F[f][nb], f: {x-qx, y-qy, z-qz, x, y, z}.  K = 6 leaves room for all three
     // split products in TWO v_mfma_f32_32x32x16_f16: k slots 0..5 of the lower lane half carry w_hi . x_hi, of the upper half w_lo . x_hi
@@ -380,8 +386,10 @@ static int pe_mlp_max_impl(const float* pts, const int* idx, int B, int N, int S
     const long want = (total + PH_WAVES - 1) / PH_WAVES;
     const long cap = (max_wg > 0 && max_wg < 768) ? max_wg : 768;
     const dim3 pgrid((unsigned)(want < cap ? want : cap));
+    // p / N inside the kernel by multiply-high: exact while p N < 2^32 (else 0: the kernel divides)
+    const unsigned ndiv = (total * (long)N < (1l << 32) && N > 1) ? (unsigned)((1ull << 32) / (unsigned long long)N) + 1u : 0u;
     hipLaunchKernelGGL(pe_mlp_max_h3_kernel, pgrid, dim3(PH_WAVES * 64), lds, (hipStream_t)stream, pts, idx, N, S, (int)total,
-                       W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off);
+                       W1, sc1, sh1, W2, sc2, sh2, W3, sc3, sh3, out, ldo, off, ndiv);
   } else {
     const size_t lds = (size_t)(PM_WFLOATS + PM_WAVES * PM_HFLOATS) * 4;
     static unsigned long long attr_set = 0;
