@@ -230,19 +230,19 @@ __global__ __launch_bounds__(XA_WAVES * 64) void xattn_kernel(XaArgs a) {
     for (int gi = 0; gi < 2; ++gi) {
       const int j = (wave + XA_WAVES * gi) * 16 + fr;
       if (wave + XA_WAVES * gi < mgroups) {
-        _Float16* row = reinterpret_cast<_Float16*>(kimg + (size_t)j * 256);
+        // channels 16 i + 4 g + r (r = 0..3) of a key are the slots 32 (i >> 1) + 8 g + 4 (i & 1) + r of its row: four consecutive halves,
+        // one 8-byte write per plane (was eight 2-byte writes)
+        unsigned char* row = kimg + (size_t)j * 256;
+        typedef unsigned xa_u2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int d = 16 * i + 4 * fg + r;
-            _Float16 hi, lo;
-            sam6d_split_f16(kacc[gi][i][r] * sk, hi, lo);
-            const int p = 32 * (d >> 5) + xa_channel_slot(d & 31);
-            const int ch = p >> 3, cl = 8 + (p >> 3);
-            row[((ch ^ (j & 15)) << 3) + (p & 7)] = hi;
-            row[((cl ^ (j & 15)) << 3) + (p & 7)] = lo;
-          }
+        for (int i = 0; i < 4; ++i) {
+          unsigned h01, l01, h23, l23;
+          sam6d_split2_f16(kacc[gi][i][0] * sk, kacc[gi][i][1] * sk, h01, l01);
+          sam6d_split2_f16(kacc[gi][i][2] * sk, kacc[gi][i][3] * sk, h23, l23);
+          const int ch = 4 * (i >> 1) + fg, cl = 8 + ch, off = 8 * (i & 1);
+          *reinterpret_cast<xa_u2*>(row + ((ch ^ (j & 15)) << 4) + off) = xa_u2{h01, h23};
+          *reinterpret_cast<xa_u2*>(row + ((cl ^ (j & 15)) << 4) + off) = xa_u2{l01, l23};
+        }
       }
     }
   } else {
