@@ -24,7 +24,13 @@ extern "C" {
 #endif
 
 const char* sam6d_last_error(void);
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header: bumped on any change of a signature OR of the size / layout of a buffer an entry reads or writes.
+ * A consumer compares sam6d_abi_version() of the loaded library with the SAM6D_ABI_VERSION it was compiled against and refuses a
+ * mismatch (sam6d_hip/_lib.py and tests/cabi/cabi_check.c do).
+ *   1  rounds 1-3
+ *   2  sam6d_set_thread_matmul_mode added; round 3's layout change made visible: sam6d_linattn_kv_pack / sam6d_linattn_kv_image write 4*B floats to `inv` (one image
+ *      scale per head), sam6d_linattn_layer reads kvinv as (B,4) -- a version-1 consumer allocated B floats */
+#define SAM6D_ABI_VERSION 2
 int sam6d_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -113,6 +119,12 @@ int sam6d_gemm_nt_b2(const float* A, const float* W, float* C, int M, int N, int
  * sam6d_fine_match) scale every operand row / matrix by a power of two instead (exact to undo). */
 int sam6d_set_matmul_mode(int mode);
 int sam6d_get_matmul_mode(void);
+/* The calling THREAD's override of the process-wide mode (same F.linear call sites, PEM/model/transformer.py:127-129): 0 / 1 / 2 as
+ * above, -1 = follow the process default again.  sam6d_get_matmul_mode() returns the override while one is set.  A host that serves
+ * two weight sets with different arithmetic in one process brackets each call sequence with it (sam6d_hip/pem.py does, from the
+ * Options object its entry points take) instead of flipping the process default under another thread's launches. */
+int sam6d_set_thread_matmul_mode(int mode);
+int sam6d_get_thread_matmul_mode(void);
 
 /* nn.LayerNorm(256) over `rows` rows (PEM/model/transformer.py:158,189,436,597).  eps as in torch (1e-5). */
 int sam6d_layernorm256(const float* x, const float* gamma, const float* beta, float* y, long rows, long ldx, long ldy,
@@ -416,6 +428,13 @@ int sam6d_ism_patch_fused_scores(const void* ws, int Ns, int P, float thred, flo
 int sam6d_ism_project(const float* masks, const int* depth, const double* K, double depth_scale, const float* poses,
                       const float* pointcloud, const int* best, const int* obj, int Ns, int H, int W, int Npc,
                       double* part_ws, int* image_vu, int* xyxy, float* translate, void* stream);
+
+/* replaces depth_image_to_pointcloud_translate_torch(depth, scale, K) itself (ISM/utils/trimesh_utils.py:77-105) for a direct caller:
+ * masked_depth (N,H,W) f32 = N already-masked depth maps (mm), K (3,3) f64 row-major, -> translate (N,3) f32 = the mean back-projected
+ * point of each map over its pixels with Z > 0 (count + 1e-8 in the denominator); float64 per-pixel terms and sums like the reference's
+ * real caller.  part_ws: N * 64 * 4 doubles of scratch.  One launch pair for all maps. */
+int sam6d_ism_translate_maps(const float* masked_depth, const double* K, double depth_scale, int N, int H, int W, double* part_ws,
+                             float* translate, void* stream);
 /* replaces compute_iou (ISM/utils/bbox_utils.py:197-222): boxes (Ns,4) int64; *all_positive = 0 when any pair has a
  * non-positive overlap (the reference then returns the scalar 0.0). */
 int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, float* iou, int* all_positive, void* stream);

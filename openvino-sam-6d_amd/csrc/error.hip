@@ -13,4 +13,4 @@ void sam6d_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sam6d_last_error(void) { return g_err; }
-extern "C" int sam6d_abi_version(void) { return 1; }
+extern "C" int sam6d_abi_version(void) { return SAM6D_ABI_VERSION; }

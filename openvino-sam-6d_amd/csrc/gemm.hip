@@ -502,12 +502,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
 // 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = fp16 x3 split (default), 2 = fp16 single product (a_hi . b_hi only, fp32
 // accumulate: the reduced-precision variant of BASELINE.json config 5, ~1e-3 relative).  Process-wide; set before launching.
 static int g_matmul_mode = 1;
+// The calling thread's override of the process default (-1 = none): a host that runs two weight sets with different arithmetic in one
+// process brackets each call sequence with sam6d_set_thread_matmul_mode(mode) ... (-1) instead of flipping the process default.
+static thread_local int t_matmul_mode = -1;
 extern "C" int sam6d_set_matmul_mode(int mode) {
   SAM6D_REQUIRE(mode == 0 || mode == 1 || mode == 2, "set_matmul_mode: 0 (exact fp32 MFMA), 1 (fp16 x3 split) or 2 (fp16 single product)");
   g_matmul_mode = mode;
   return 0;
 }
-extern "C" int sam6d_get_matmul_mode(void) { return g_matmul_mode; }
+extern "C" int sam6d_set_thread_matmul_mode(int mode) {
+  SAM6D_REQUIRE(mode >= -1 && mode <= 2, "set_thread_matmul_mode: -1 (follow the process default), 0, 1 or 2");
+  t_matmul_mode = mode;
+  return 0;
+}
+extern "C" int sam6d_get_matmul_mode(void) { return t_matmul_mode >= 0 ? t_matmul_mode : g_matmul_mode; }
+extern "C" int sam6d_get_thread_matmul_mode(void) { return t_matmul_mode; }
 
 static int gemm_launch(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                        float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
@@ -540,7 +549,7 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
 #define GEMM_LAUNCH(KERNEL, ...)                                                                                         \
   hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, A, W, bias, colscale, residual, C, M, N, K, lda, ldw, ldc, ldr, sA, sW, \
                      sC, sR, divisor, act, b2, ##__VA_ARGS__)
-  if (g_matmul_mode >= 1 && K >= 32) {
+  if (sam6d_get_matmul_mode() >= 1 && K >= 32) {
     const int half = (sam6d_half_for(0) && !keep_split) ? 1 : 0;
     // 16-byte epilogue accesses need 4-float alignment of every row start and of the per-column vectors
     const int wide = ((N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && (b2.sC2 & 3) == 0 && (((size_t)C) & 15) == 0 &&
@@ -749,7 +758,7 @@ extern "C" int sam6d_gemm_ln256(const float* A, const float* W, const float* bia
   SAM6D_REQUIRE(M >= 0 && K >= 32 && (K % 32) == 0, "gemm_ln256: K must be a positive multiple of 32 (got %d)", K);
   SAM6D_REQUIRE(lda >= K && ldw >= K && ldy >= 256 && (!residual || ldr >= 256), "gemm_ln256: leading dimension too small");
   SAM6D_REQUIRE(((lda | ldw) & 3) == 0 && ((((size_t)A) | ((size_t)W)) & 15) == 0, "gemm_ln256: A and W rows must be 16-byte aligned");
-  SAM6D_REQUIRE(g_matmul_mode >= 1, "gemm_ln256: split-precision mode only (use sam6d_gemm_nt + sam6d_layernorm256 in mode 0)");
+  SAM6D_REQUIRE(sam6d_get_matmul_mode() >= 1, "gemm_ln256: split-precision mode only (use sam6d_gemm_nt + sam6d_layernorm256 in mode 0)");
   if (M == 0) return 0;
   hipLaunchKernelGGL(gemm_ln_h3_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, A, W, bias, residual, gamma,
                      beta, Y, M, K, lda, ldw, ldr, ldy, eps);

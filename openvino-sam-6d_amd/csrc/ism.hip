@@ -527,6 +527,56 @@ extern "C" int sam6d_ism_project(const float* masks, const int* depth, const dou
   SAM6D_LAUNCH_CHECK("ism_project");
 }
 
+// depth_image_to_pointcloud_translate_torch as the reference defines it (trimesh_utils.py:77-105): N already-masked depth maps in, N mean
+// back-projected points out -- one launch for all maps (the per-pixel terms and sums in double like the kernel above).
+__global__ __launch_bounds__(256) void ism_translate_maps_kernel(const float* __restrict__ md, const double* __restrict__ K, double scale,
+                                                                 int H, int Wd, double* __restrict__ part) {
+  __shared__ double red[4][4];
+  const int i = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
+  const long npx = (long)H * Wd;
+  const long per = (npx + ISM_TCH - 1) / ISM_TCH;
+  const long p0 = ch * per, p1 = min(npx, p0 + per);
+  const float* m = md + (size_t)i * npx;
+  const double cx = K[2], fx = K[0], cy = K[5], fy = K[4];
+  double sx = 0, sy = 0, sz = 0, sn = 0;
+  for (long p = p0 + t; p < p1; p += 256) {
+    const double Z = (double)m[p] * scale / 1000.0;
+    if (Z > 0.0) {
+      const int u = (int)(p % Wd), v = (int)(p / Wd);
+      sx += ((double)u - cx) * Z / fx;
+      sy += ((double)v - cy) * Z / fy;
+      sz += Z;
+      sn += 1.0;
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); sn = wave_sum(sn);
+  if ((t & 63) == 0) { red[0][t >> 6] = sx; red[1][t >> 6] = sy; red[2][t >> 6] = sz; red[3][t >> 6] = sn; }
+  __syncthreads();
+  if (t < 4) part[((size_t)i * ISM_TCH + ch) * 4 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+}
+__global__ __launch_bounds__(64) void ism_translate_finish_kernel(const double* __restrict__ part, int N, float* __restrict__ translate) {
+  const int e = blockIdx.x * 64 + threadIdx.x;  // over N * 3
+  if (e >= N * 3) return;
+  const int i = e / 3, t = e % 3;
+  double s = 0, n = 0;
+  for (int c = 0; c < ISM_TCH; ++c) {
+    s += part[((size_t)i * ISM_TCH + c) * 4 + t];
+    n += part[((size_t)i * ISM_TCH + c) * 4 + 3];
+  }
+  translate[e] = (float)(s / (n + 1e-8));
+}
+
+extern "C" int sam6d_ism_translate_maps(const float* masked_depth, const double* K, double depth_scale, int N, int H, int W,
+                                        double* part_ws, float* translate, void* stream) {
+  SAM6D_REQUIRE(masked_depth && K && part_ws && translate, "ism_translate_maps: null pointer");
+  SAM6D_REQUIRE(N >= 0 && N <= 65535 && H > 0 && W > 0, "ism_translate_maps: bad sizes");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ism_translate_maps_kernel, dim3(ISM_TCH, N), dim3(256), 0, s, masked_depth, K, depth_scale, H, W, part_ws);
+  hipLaunchKernelGGL(ism_translate_finish_kernel, dim3(cdiv(N * 3, 64)), dim3(64), 0, s, part_ws, N, translate);
+  SAM6D_LAUNCH_CHECK("ism_translate_maps");
+}
+
 // IoU of the projected-template box with the proposal box (bbox_utils.py:197-222), integer arithmetic as in the
 // reference; `all_positive` (device int, pre-set to 1 here) is cleared when any pair has a non-positive overlap --
 // the caller turns that into the reference's scalar-0.0 result (:214-220).  final = (sem + appe + iou*vis)/(2 + vis).

@@ -817,6 +817,7 @@ __device__ __forceinline__ unsigned sr_key(float d) {
   const unsigned u = __float_as_uint(d);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+#define SR_STATIC_LDS (2048 * 4 + 64)  // hist[] + the three scalars of select_radix_kernel, padded
 __global__ __launch_bounds__(SR_T) void select_radix_kernel(const float* __restrict__ dis, int n, int k, int* __restrict__ sel) {
   extern __shared__ unsigned sr_keys[];        // n keys, then k candidate ids, then k candidate keys
   __shared__ int hist[2048];
@@ -916,7 +917,8 @@ extern "C" int sam6d_select_smallest(const float* dis, int B, int n, int k, int*
     const char* e = getenv("SAM6D_SELECT_RADIX");  // A/B switch: 0 = the all-pairs rank counting
     use_radix = (e && e[0] == '0') ? 0 : 1;
   }
-  if (use_radix && (size_t)(n + 2 * k) * 4 <= 60000)  // (the default dynamic-LDS limit; longer rows keep the all-pairs kernel)
+  // dynamic + static LDS (hist[2048] + 3 words, rounded up) within the default 64 KB limit; longer rows keep the all-pairs kernel
+  if (use_radix && (size_t)(n + 2 * k) * 4 + SR_STATIC_LDS <= 65536)
     hipLaunchKernelGGL(select_radix_kernel, dim3(B), dim3(SR_T), (size_t)(n + 2 * k) * 4, (hipStream_t)stream, dis, n, k, sel);
   else
     hipLaunchKernelGGL(select_smallest_kernel, dim3(cdiv(n, 256), B), dim3(256), (size_t)((n + 3) & ~3) * 4, (hipStream_t)stream, dis, n, k,
@@ -1164,6 +1166,16 @@ extern "C" int sam6d_score_select_hypotheses_ws(const int* sel, const float* Rs,
   const int Ppad = (P + 31) & ~31;
   const long tiles = ((long)k * N1 + 31) / 32;
   const int wgs = (int)((tiles + SM_WAVES * SM_CT - 1) / (SM_WAVES * SM_CT));
+  static unsigned long long shm_done = 0;  // P = 4096 needs 80 KB of dynamic LDS: above the default 64 KB limit
+  if (sam6d_first_use_on_device(&shm_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_hyp_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       4096 * 20);
+    if (e != hipSuccess) {
+      sam6d_set_error("score_select_hypotheses_ws: cannot reserve LDS: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&shm_done);
+  }
   hipLaunchKernelGGL(score_hyp_mfma_kernel, dim3(wgs, B), dim3(SM_WAVES * 64), (size_t)Ppad * 20, s, sel, Rs, ts, pts1, w1, model, radius, N1,
                      P, Ppad, nh, k, ws);
   SAM6D_LAUNCH_CHECK_CONT("score_select_hypotheses_ws(score)");

@@ -46,8 +46,11 @@ class Net(nn.Module):
             object.__setattr__(self, "_pack_sig", sig)
         return self._pack
 
-    def match(self, dense_pm, dense_fm, dense_po, dense_fo, radius, model):
-        """The post-feature-extraction seam (pose_estimation_model.py:29-55): the hot path proper."""
+    def match(self, dense_pm, dense_fm, dense_po, dense_fo, radius, model, template_ids=None):
+        """The post-feature-extraction seam (pose_estimation_model.py:29-55): the hot path proper.
+        template_ids (B,): a multi-object batch -- dense_po / dense_fo hold the T unique templates (the `all_dense_po[obj]` form of the
+        BOP provider, PEM/provider/bop_test_dataset.py:107,156, before it is indexed per instance) and proposal b uses template
+        template_ids[b]; bit-identical to the per-instance repeated form."""
         if self.fused and self.coarse_npoint == 196:
             if self.training:
                 raise RuntimeError("inference only: call .eval() (the reference fork is inference-only too, README.md:78-84)")
@@ -60,10 +63,17 @@ class Net(nn.Module):
                        angle_k=self.geo_embedding.angle_k)
             # the reference's caller repeats one object's template tensors per instance (run_inference_custom_pytorch.py:445-446):
             # recognised here (bitwise comparison on the device), their pose-independent work then runs once
+            if template_ids is not None:
+                return _pem.pem_match(dense_pm.contiguous(), dense_fm.contiguous(), dense_po.contiguous(), dense_fo.contiguous(),
+                                      radius.reshape(-1).contiguous(), model.contiguous(), W, rand.contiguous(), cfg=cfg,
+                                      template_ids=template_ids)
             shared = _pem.template_is_shared(dense_po, dense_fo) if self.shared_template is None else bool(self.shared_template)
             return _pem.pem_match(dense_pm.contiguous(), dense_fm.contiguous(), dense_po.contiguous(), dense_fo.contiguous(),
                                   radius.reshape(-1).contiguous(), model.contiguous(), W, rand.contiguous(), cfg=cfg,
                                   shared_template=shared)
+        if template_ids is not None:  # module-by-module path: the repeated form
+            ids = template_ids.to(dense_po.device).long()
+            dense_po, dense_fo = dense_po[ids], dense_fo[ids]
         bg_point = torch.ones(dense_pm.size(0), 1, 3, device=dense_pm.device) * 100
         sparse_pm, sparse_fm, fps_idx_m = sample_pts_feats(dense_pm, dense_fm, self.coarse_npoint, return_index=True)
         geo_m = self.geo_embedding(torch.cat([bg_point, sparse_pm], dim=1))

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("SAM6D_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
+ABI_VERSION = 2  # include/sam6d_hip.h SAM6D_ABI_VERSION (tests/test_abi.py keeps the two equal)
 c_l = ctypes.c_long
 c_p = ctypes.c_void_p
 
@@ -29,6 +30,7 @@ SIGNATURES = {
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_gemm_nt_w16": [c_p] * 4 + [c_f] + [c_p] * 4 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_set_matmul_mode": [c_i],
+    "sam6d_set_thread_matmul_mode": [c_i],
     "sam6d_layernorm256": [c_p, c_p, c_p, c_p, c_l, c_l, c_l, c_f, c_p],
     "sam6d_gemm_ln256": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_l, c_l, c_l, c_f, c_p],
     "sam6d_geo_embedding": [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_p, c_p, c_p, c_p],
@@ -78,6 +80,7 @@ SIGNATURES = {
     "sam6d_ism_patch_fused": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, ctypes.c_size_t, c_p],
     "sam6d_ism_patch_fused_scores": [c_p, c_i, c_i, c_f, c_p, c_p, c_p],
     "sam6d_ism_project": [c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "sam6d_ism_translate_maps": [c_p, c_p, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "sam6d_radius_normalize": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
@@ -133,8 +136,14 @@ def load():
     lib.sam6d_last_error.restype = ctypes.c_char_p
     lib.sam6d_last_error.argtypes = []
     lib.sam6d_abi_version.restype = c_i
+    lib.sam6d_abi_version.argtypes = []
+    if lib.sam6d_abi_version() != ABI_VERSION:
+        raise ImportError("libsam6d_hip.so has ABI version %d, this binding was written for %d (include/sam6d_hip.h SAM6D_ABI_VERSION): "
+                          "rebuild the library" % (lib.sam6d_abi_version(), ABI_VERSION))
     lib.sam6d_get_matmul_mode.restype = c_i
     lib.sam6d_get_matmul_mode.argtypes = []
+    lib.sam6d_get_thread_matmul_mode.restype = c_i
+    lib.sam6d_get_thread_matmul_mode.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args

@@ -125,6 +125,19 @@ def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, dep
 
 
 @on_tensor_device
+def translate_masked_depth_maps(masked_depth, K, depth_scale):
+    """ISM/utils/trimesh_utils.py:77-105 for all N already-masked depth maps (N,H,W) in one launch -> translate (N,3) f32."""
+    N, H, W = masked_depth.shape
+    dev = masked_depth.device
+    md = masked_depth.to(torch.float32).contiguous()
+    Kd = torch.as_tensor(K).to(device=dev, dtype=torch.float64).contiguous()
+    part = torch.empty(max(N, 1) * 64 * 4, dtype=torch.float64, device=dev)
+    tr = torch.empty(N, 3, dtype=torch.float32, device=dev)
+    _lib.call("sam6d_ism_translate_maps", _p(md), Kd.data_ptr(), float(depth_scale), N, H, W, part.data_ptr(), _p(tr), _s())
+    return tr
+
+
+@on_tensor_device
 def compute_iou(xyxy, boxes):
     """ISM/utils/bbox_utils.py:197-222 incl. the quirk: any non-positive overlap => the python float 0.0."""
     Ns = xyxy.shape[0]

@@ -23,25 +23,92 @@ def _s():
     return torch.cuda.current_stream().cuda_stream
 
 
-class _Flags:
-    """The process-wide switches a launch sequence depends on (the matmul mode of the library, the A/B environment variables), read
-    ONCE per public entry point instead of once per launch: the host issues ~250 launches per step and must stay ahead of the GPU."""
-    __slots__ = ("mode", "w16", "fused_block", "fused_ln", "fused_front", "xattn_kv", "score_mfma", "bq_grid", "rpe_products", "self_attn", "fused_out", "rows_linear")
+class Options:
+    """The explicit choice of arithmetic and kernel routes for a launch sequence -- what used to be a process-global matmul mode plus
+    a dozen SAM6D_* environment switches.  An Options object travels with a weight set (`PemWeights(sd, dev, options=...)`) or with one
+    call (`pem_match(..., options=...)`, any @on_tensor_device entry point); two weight sets in one process can therefore run different
+    arithmetic.  Without one, `Options.from_env()` is resolved once per outermost entry point (the A/B switches of earlier rounds keep
+    working from the environment).  Fields:
+      matmul_mode   None = the library's process default (sam6d_set_matmul_mode / SAM6D_MATMUL_MODE), else 0 exact fp32 MFMA,
+                    1 fp16 x3 split, 2 fp16 single product (experimental); applied as the calling thread's mode for the duration of
+                    the entry point (sam6d_set_thread_matmul_mode)
+      fused_rpe / fused_fine / overlap / microbatch / pe_side_wgs   pipeline shape of pem_match (cfg keys of the same name win)
+      the rest      A/B routes between bit- or tolerance-equivalent kernels (see the comments below)."""
+    DEFAULTS = dict(
+        matmul_mode=None,
+        w16=True,           # pre-split fp16 weight halves in the large GEMMs
+        fused_block=True,   # fused transformer-block kernels (csrc/block.hip)
+        fused_ln=False,     # projection + residual + LayerNorm in one launch on the unfused path (measured 1 % slower)
+        fused_front=True,   # qkv projection + proj_p fold + D_c fold of an RPE self layer in one launch
+        score_mfma=True,    # hypothesis scoring: distance products on the fp32 matrix cores
+        bq_grid=True,       # ball queries through the cell grid (identical indices)
+        xattn_kv=True,      # key / value projection inside the cross-attention kernel
+        self_attn=True,     # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
+        fused_out=True,     # fine out_proj + normalize + operand split in one pass
+        rows_linear=True,   # sparse-token projections on the panel kernel
+        cross_fused=True,   # a cross layer's attention + layer tail in one launch (csrc/xblock.hip)
+        rpe_products=0,     # 0: what the weight set allows (geo_cheb_a_packed); 3: always three stage-1 products
+        fused_rpe=True,     # RPE attention without the embedding tensor
+        fused_fine=True,    # fine similarity + soft assignment as one pipeline (finematch.hip)
+        overlap=True,       # pose-independent fine work on a second HIP stream
+        microbatch=1,
+        pe_side_wgs=512,    # bound on the side stream's persistent PE-MLP workgroups
+    )
+    ENV = dict(matmul_mode="SAM6D_MATMUL_MODE", w16="SAM6D_W16", fused_block="SAM6D_FUSED_BLOCK", fused_ln="SAM6D_FUSED_LN",
+               fused_front="SAM6D_FUSED_FRONT", score_mfma="SAM6D_SCORE_MFMA", bq_grid="SAM6D_BQ_GRID", xattn_kv="SAM6D_XATTN_KV",
+               self_attn="SAM6D_SELF_ATTN", fused_out="SAM6D_FUSED_OUT", rows_linear="SAM6D_ROWS_LINEAR", cross_fused="SAM6D_CROSS_FUSED",
+               rpe_products="SAM6D_RPE_PRODUCTS", fused_rpe="SAM6D_FUSED_RPE", fused_fine="SAM6D_FUSED_FINE", overlap="SAM6D_OVERLAP",
+               microbatch="SAM6D_MICROBATCH", pe_side_wgs="SAM6D_PE_SIDE_WGS")
+    __slots__ = tuple(DEFAULTS) + ("mode",)
 
-    def __init__(self):
-        env = os.environ.get
-        self.mode = int(_lib.load().sam6d_get_matmul_mode())
-        self.w16 = self.mode >= 1 and env("SAM6D_W16", "1") == "1"
-        self.fused_block = self.mode >= 1 and env("SAM6D_FUSED_BLOCK", "1") == "1"
-        self.fused_ln = self.mode >= 1 and env("SAM6D_FUSED_LN", "0") == "1"
-        self.fused_front = self.fused_block and env("SAM6D_FUSED_FRONT", "1") == "1"
-        self.score_mfma = env("SAM6D_SCORE_MFMA", "1") == "1"  # hypothesis scoring: distance products on the fp32 matrix cores
-        self.bq_grid = env("SAM6D_BQ_GRID", "1") == "1"  # ball queries through the cell grid (identical indices)
-        self.xattn_kv = env("SAM6D_XATTN_KV", "1") == "1"  # key / value projection inside the cross-attention kernel
-        self.self_attn = env("SAM6D_SELF_ATTN", "1") == "1"  # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
-        self.fused_out = self.fused_block and env("SAM6D_FUSED_OUT", "1") == "1"  # fine out_proj + normalize + operand split in one pass
-        self.rows_linear = self.fused_block and env("SAM6D_ROWS_LINEAR", "1") == "1"  # sparse-token projections on the panel kernel
-        self.rpe_products = int(env("SAM6D_RPE_PRODUCTS", "0"))  # 0: what the weight set allows (geo_cheb_a_packed); 3: always three
+    def __init__(self, **kw):
+        bad = set(kw) - set(self.DEFAULTS)
+        if bad:
+            raise TypeError("Options: unknown field(s) %s" % sorted(bad))
+        for k, v in self.DEFAULTS.items():
+            setattr(self, k, kw.get(k, v))
+        self._resolve()
+
+    def _resolve(self):
+        """Resolve the arithmetic mode and gate the routes that exist only in the split-precision modes."""
+        m = self.matmul_mode
+        self.mode = int(_lib.load().sam6d_get_matmul_mode()) if m is None else int(m)
+        if self.mode not in (0, 1, 2):
+            raise ValueError("Options.matmul_mode must be None, 0, 1 or 2")
+        split = self.mode >= 1
+        self.w16 = bool(self.w16) and split
+        self.fused_block = bool(self.fused_block) and split
+        self.fused_ln = bool(self.fused_ln) and split
+        self.fused_front = bool(self.fused_front) and self.fused_block
+        self.fused_out = bool(self.fused_out) and self.fused_block
+        self.rows_linear = bool(self.rows_linear) and self.fused_block
+        self.cross_fused = bool(self.cross_fused) and self.fused_block
+        self.fused_rpe = bool(self.fused_rpe) and split
+        self.rpe_products = int(self.rpe_products)
+        self.microbatch = int(self.microbatch)
+        self.pe_side_wgs = int(self.pe_side_wgs)
+
+    @classmethod
+    def from_env(cls, **over):
+        """The environment's A/B switches (read now), overridden by keyword arguments."""
+        kw = {}
+        for k, name in cls.ENV.items():
+            v = os.environ.get(name)
+            if v is None:
+                continue
+            d = cls.DEFAULTS[k]
+            kw[k] = int(v) if (d is None or (isinstance(d, int) and not isinstance(d, bool))) else (v == "1")
+        kw.update(over)
+        return cls(**kw)
+
+    def replace(self, **over):
+        kw = {k: getattr(self, k) for k in self.DEFAULTS}
+        kw["matmul_mode"] = self.matmul_mode
+        kw.update(over)
+        return Options(**kw)
+
+    def describe(self):
+        return {k: getattr(self, k) for k in self.DEFAULTS if k != "matmul_mode"} | {"matmul_mode": self.mode}
 
 
 _FLAGS = None
@@ -49,20 +116,28 @@ _DEPTH = 0
 
 
 def _flags():
-    """Inside a public entry point (on_tensor_device): the switches as they were when it was entered; outside: read afresh."""
-    global _FLAGS
+    """Inside a public entry point (on_tensor_device): the Options it was entered with; outside: the environment's, read afresh."""
     if _FLAGS is not None:
         return _FLAGS
-    f = _Flags()
-    if _DEPTH > 0:
-        _FLAGS = f
-    return f
+    return Options.from_env()
+
+
+def _find_options(args, kwargs):
+    o = kwargs.pop("options", None)
+    if o is not None:
+        return o
+    for a in list(args) + list(kwargs.values()):
+        o = getattr(a, "options", None)
+        if isinstance(o, Options):
+            return o
+    return None
 
 
 def on_tensor_device(fn):
     """Run `fn` with the device of its first tensor argument current: the launches go to torch's current stream OF THAT DEVICE and
     torch.empty workspaces land there, also when the caller's current device is another GPU of the node.  The outermost decorated call
-    also fixes the process-wide switches (_flags) for its whole launch sequence."""
+    also fixes the Options of its whole launch sequence -- the `options=` keyword, else the `.options` of a weight-set argument, else
+    the environment's -- and makes their arithmetic mode the calling thread's (sam6d_set_thread_matmul_mode) until it returns."""
     import functools
 
     @functools.wraps(fn)
@@ -71,14 +146,21 @@ def on_tensor_device(fn):
         dev = next((a.device for a in args if torch.is_tensor(a)), None)
         if dev is None or dev.type != "cuda":
             raise RuntimeError("%s: needs HIP device tensors (this build has no CPU path)" % fn.__name__)
+        opts = _find_options(args, kwargs)
+        outer = _DEPTH == 0
+        if outer:
+            _FLAGS = opts if opts is not None else Options.from_env()
+            prev_mode = int(_lib.load().sam6d_get_thread_matmul_mode())
+            _lib.call("sam6d_set_thread_matmul_mode", _FLAGS.mode)
         _DEPTH += 1
         try:
             with torch.cuda.device(dev):
                 return fn(*args, **kwargs)
         finally:
             _DEPTH -= 1
-            if _DEPTH == 0:
+            if outer:
                 _FLAGS = None
+                _lib.call("sam6d_set_thread_matmul_mode", prev_mode)
     return wrapper
 
 
@@ -215,9 +297,11 @@ class PemWeights:
     (SURVEY 8b B2).  Packing is pure data movement: concatenating q/k/v projection weights, transposing proj_p, folding
     eval-mode BatchNorm into a per-channel scale/shift."""
 
-    def __init__(self, sd, device, nblock=3):
+    def __init__(self, sd, device, nblock=3, options=None):
+        """options: the Options every launch sequence on this weight set runs with (None: the environment's, per call)."""
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
         self.dev = device
+        self.options = options
         self.nblock = nblock
         self.div_term = g("geo_embedding.embedding.div_term")
         self.geo_d = Linear(g("geo_embedding.proj_d.weight"), g("geo_embedding.proj_d.bias"))
@@ -1166,6 +1250,19 @@ def _tokens_with_bg(x, lin, bg, extra=None):
     return T
 
 
+def _expand_blocks(src, gidx):
+    """src (U, ...) -> (len(gidx), ...) with out[j] = src[gidx[j]] (whole leading blocks, any dtype): how per-template results are handed
+    to the proposals that share the template (a device copy, no arithmetic; sam6d_take_rows)."""
+    src = src.contiguous()
+    M = gidx.shape[0]
+    out = torch.empty((M,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src.element_size()
+    for d in src.shape[1:]:
+        row_bytes *= d
+    _lib.call("sam6d_take_rows", src.data_ptr(), gidx.data_ptr(), src.shape[0], M, row_bytes, out.data_ptr(), _s())
+    return out
+
+
 def coarse_point_matching(sp, sf, E, radius, model, W, rand, cfg, return_aux=False, before_pose=None):
     """sp (2B,n,3), sf (2B,n,256) stacked [scene; template]  (PEM/model/coarse_point_matching.py:32-63, eval).
     before_pose: optional callable run between the transformer and the pose solver (pem_match queues side-stream work there)."""
@@ -1187,6 +1284,21 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
     """First half of fine_static: token buffer D with in_proj of both clouds + the template cloud's ball queries (ordinary
     grids that share the chip well).  df: stacked (2B,N,256) or the (scene, template) pair.  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
     dense_fo `.repeat`ed per instance, PEM/run_inference_custom_pytorch.py:445-446): its tokens are computed once, in slot B."""
+    if isinstance(shared_template, tuple):
+        # (B, T, gidx): dp = [B scene clouds; T UNIQUE template clouds], df = (scene (B,N,256), template (T,N,256)).  The scene tokens go
+        # to slots 0 .. B-1 of D (2B slots); the T template token blocks are finished in their own buffer Dt (in_proj here, the PE MLPs
+        # in fine_static_b) and then handed to the template slot of every proposal (fine_static_b).
+        B, T, _ = shared_template
+        N, K = df[0].shape[1], df[0].shape[2]
+        lin = W.fine["in_proj"]
+        D = _empty((2 * B, N + 1, C), df[0])
+        Dt = _empty((T, N + 1, C), df[0])
+        gemm(df[0], lin.w, lin.b, D, N, C, K, K, K, C, c_off=C, batch=B, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+        gemm(df[1], lin.w, lin.b, Dt, N, C, K, K, K, C, c_off=C, batch=T, sA=N * K, sC=(N + 1) * C, w16=lin.w16())
+        _lib.call("sam6d_put_rows", _p(W.fine["bg"]), 0, C, _p(D), (N + 1) * C, C, B, 1, C, _s())
+        _lib.call("sam6d_put_rows", _p(W.fine["bg"]), 0, C, _p(Dt), (N + 1) * C, C, T, 1, C, _s())
+        grp = pe_group(dp[B:], cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"], cfg["pe_nsample2"])
+        return (D, Dt), grp
     if isinstance(df, tuple):
         B, N, K = df[0].shape
         Bp = 2 * B
@@ -1213,6 +1325,13 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
 def fine_static_b(dp, D, grp, W, shared_template=False, max_wg=0):
     """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run).
     shared_template: one cloud's worth, then the finished token block of slot B is copied to the other template slots."""
+    if isinstance(shared_template, tuple):
+        B, T, gidx = shared_template
+        D, Dt = D
+        N = dp.shape[1]
+        pe_apply(dp[B:], grp, W, Dt, C, (N + 1) * C, max_wg)
+        _lib.call("sam6d_take_rows", Dt.data_ptr(), gidx.data_ptr() + 8 * B, T, B, (N + 1) * C * 4, _p(D, B * (N + 1) * C), _s())
+        return D
     Bp, N, _ = dp.shape
     B = Bp // 2
     if shared_template and B > 1:
@@ -1313,7 +1432,7 @@ DEFAULT_CFG = dict(coarse_npoint=196, sigma_d=0.2, sigma_a=15, angle_k=3, temp=0
 
 @on_tensor_device
 def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cfg=DEFAULT_CFG, return_aux=False,
-              shared_template=False, init_pose=None):
+              shared_template=False, init_pose=None, template_ids=None):
     """Net.forward after feature extraction (PEM/model/pose_estimation_model.py:29-55):
     FPS x2 -> geo-embedding x2 -> CoarsePointMatching -> FinePointMatching -> (pred_R, pred_t, pred_pose_score).
     rand (B, 3*nproposal1) uniforms for the hypothesis sampling (the reference draws them inside, model_utils.py:292).
@@ -1332,16 +1451,38 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     fine labels / weights) WITHOUT changing which kernels run.  Kernel choice is cfg's: cfg["fused_rpe"] (env SAM6D_FUSED_RPE, default on)
     = RPE attention without the embedding tensor, cfg["fused_fine"] (env SAM6D_FUSED_FINE, default on) = the similarity + soft-assignment
     pipeline of finematch.hip; off = the materialised launch-per-op forms.
+    template_ids (B,) integer tensor: a MULTI-OBJECT batch (a BOP scene mixes objects per batch: PEM/provider/bop_test_dataset.py:107,156
+    returns an `obj` index per instance).  dense_po (T,N,3) / dense_fo (T,N,256) then hold the T UNIQUE templates and proposal b uses
+    template template_ids[b] -- the form the reference's caller would have BEFORE it `.repeat`s / indexes the template tensors per
+    instance (run_inference_custom_pytorch.py:445-446).  Template-side work that does not depend on the proposal -- FPS and the row
+    gathers of the sparse points / features, in_proj of the dense tokens, both ball queries, both PE MLPs, mlp3 -- runs once per
+    template and its result is handed to every proposal of that template (device copies); every kernel treats a cloud independently of
+    its batch neighbours, so the result is bit-identical to the repeated form (tests/test_configs_gpu.py).
     init_pose = (R0 (B,3,3), t0 (B,3)): the fine stage starts from this pose instead of the coarse stage's own result (which is still
     computed and returned in aux) -- the seam FinePointMatching.forward takes its init_R / init_t through
     (PEM/model/fine_point_matching.py:42-46); used by the staged parity tests."""
     B = dense_pm.shape[0]
-    mb = int(cfg.get("microbatch", os.environ.get("SAM6D_MICROBATCH", "1")))
-    fused = cfg.get("fused_rpe", os.environ.get("SAM6D_FUSED_RPE", "1") == "1") and _lib.load().sam6d_get_matmul_mode() >= 1
-    fused = fused and fused_rpe_in_range(W)
-    fused_fine = bool(cfg.get("fused_fine", os.environ.get("SAM6D_FUSED_FINE", "1") == "1"))
-
-    overlap = cfg.get("overlap", os.environ.get("SAM6D_OVERLAP", "1") == "1")
+    opts = _flags()
+    mb = int(cfg.get("microbatch", opts.microbatch))
+    fused = cfg.get("fused_rpe", opts.fused_rpe) and opts.mode >= 1
+    fused = fused and fused_rpe_in_range(W, cfg["sigma_a"])  # (the range of the angular indices, hence the guard, depends on sigma_a)
+    fused_fine = bool(cfg.get("fused_fine", opts.fused_fine))
+    overlap = cfg.get("overlap", opts.overlap)
+    tmpl = None
+    if template_ids is not None:
+        if shared_template:
+            raise ValueError("pem_match: template_ids and shared_template are alternatives")
+        T = dense_po.shape[0]
+        if dense_fo.shape[0] != T or template_ids.numel() != B:
+            raise ValueError("pem_match: template_ids (B,) indexes dense_po / dense_fo (T, ...)")
+        ids = template_ids.to(device=dense_pm.device, dtype=torch.int64).reshape(B)
+        if bool(((ids < 0) | (ids >= T)).any()):  # (one host read-back per call; an out-of-range id would otherwise read a zero block)
+            raise ValueError("pem_match: template_ids out of range [0, %d)" % T)
+        # block b of a stacked (2B, ...) tensor comes from block gidx[b] of the unique (B + T, ...) one
+        gidx = torch.cat([torch.arange(B, device=ids.device, dtype=torch.int64), ids + B]).contiguous()
+        tmpl = (B, T, gidx)
+        shared_template = tmpl
+        mb = 1
 
     def fork_fine_static(dp, df, side_key):
         """The pose-independent part of the fine stage (dense in_proj, template-cloud ball queries + PE MLP) on a second HIP
@@ -1361,10 +1502,14 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         persistent PE-MLP workgroups, which would keep the LDS-heavy outlier-embedding kernels of this phase waiting) is queued
         by rest() beside the coarse pose solver.  The micro-batch mode keeps this phase serial."""
         b = hi - lo
-        dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
-        # the features (2 x 67 MB at B = 32) stay where they are: their consumers -- the FPS row gather and the fine in_proj -- read the
-        # two halves with one launch each (a stacked copy cost 0.27 GB of traffic at the head of every step)
-        df = (dense_fm[lo:hi], dense_fo[lo:hi])
+        if tmpl is not None:
+            dp = _cat0(dense_pm, dense_po)  # (B + T, N, 3): the unique clouds
+            df = (dense_fm, dense_fo)
+        else:
+            dp = _cat0(dense_pm[lo:hi], dense_po[lo:hi])
+            # the features (2 x 67 MB at B = 32) stay where they are: their consumers -- the FPS row gather and the fine in_proj -- read the
+            # two halves with one launch each (a stacked copy cost 0.27 GB of traffic at the head of every step)
+            df = (dense_fm[lo:hi], dense_fo[lo:hi])
         early = None
         if side_key is not None and overlap:
             cur = torch.cuda.current_stream()
@@ -1374,6 +1519,11 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
                 D, grp = fine_static_a(dp, df, W, cfg, shared_template)
         n = cfg["coarse_npoint"]
         sp, sf, idx = sample_pts_feats(dp, df, n)
+        dpu = dp
+        if tmpl is not None:
+            # FPS + gathers ran once per unique cloud; every proposal now gets its template's sparse points / features / indices and the
+            # stacked (2B, N, 3) point tensor the rest of the pipeline addresses
+            sp, sf, idx, dp = (_expand_blocks(x, tmpl[2]) for x in (sp, sf, idx, dp))
         pb = _empty((2 * b, n + 1, 3), dp)
         _lib.call("sam6d_prepend_bg_point", _p(sp), 2 * b, n, _p(pb), _s())
         if fused:
@@ -1381,12 +1531,13 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         else:
             E = geo_embedding(pb, W, cfg["sigma_d"], cfg["sigma_a"], cfg["angle_k"])
         if side_key is not None and overlap:
-            D.record_stream(cur)
+            for x in (D if isinstance(D, tuple) else (D,)):
+                x.record_stream(cur)
             early = (D, side, grp)
-        return dp, df, sp, sf, idx, E, early
+        return dp, df, sp, sf, idx, E, early, dpu
 
     def rest(prep, lo, hi, side_key):
-        dp, df, sp, sf, idx, E, early = prep
+        dp, df, sp, sf, idx, E, early, dpu = prep
         rad, mod, rnd = radius[lo:hi].contiguous(), model[lo:hi].contiguous(), rand[lo:hi].contiguous()
         # The coarse stage is a chain of small launches (197-token layers, 6000 hypotheses) that leaves most of the chip
         # idle; the static part of the fine stage runs beside it (forked here unless prepare already did).
@@ -1404,16 +1555,20 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
                 ev.record(cur)
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
-                    fine_static_b(dp, D, grp, W, shared_template, max_wg=int(os.environ.get("SAM6D_PE_SIDE_WGS", "512")))
+                    fine_static_b(dpu, D, grp, W, shared_template, max_wg=opts.pe_side_wgs)
         elif overlap:
-            D, side = fork_fine_static(dp, df, side_key)
+            D, side = fork_fine_static(dpu, df, side_key)
+        elif tmpl is not None:
+            D = fine_static(dpu, df, W, cfg, shared_template)
         c = coarse_point_matching(sp, sf, E, rad, mod, W, rnd, cfg, return_aux, before_pose=hook)
         R0, t0 = c[0], c[1]
-        if D is not None:
+        if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        if isinstance(D, tuple):
+            D = D[0]  # (fine_static_b has filled the template slots from the per-template buffer)
         Ri, ti = (R0, t0) if init_pose is None else (init_pose[0][lo:hi].contiguous(), init_pose[1][lo:hi].contiguous())
-        f = fine_point_matching(dp, df, E, idx, rad, mod, Ri, ti, W, cfg, return_aux, D=D, shared_template=shared_template,
-                                fused_fine=fused_fine)
+        f = fine_point_matching(dp, df, E, idx, rad, mod, Ri, ti, W, cfg, return_aux, D=D,
+                                shared_template=(False if tmpl is not None else shared_template), fused_fine=fused_fine)
         if return_aux:
             b = hi - lo
             return f[0], f[1], f[2], dict(coarse=c[2], fine=f[3], init_R=R0, init_t=t0, fps_idx_m=idx[:b], fps_idx_o=idx[b:],
@@ -1422,12 +1577,12 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
 
     dense_pm, dense_fm, dense_po, dense_fo = [x.contiguous() for x in (dense_pm, dense_fm, dense_po, dense_fo)]
     if mb <= 1 or B < 8 * mb or return_aux:
-        if _lib.load().sam6d_get_matmul_mode() >= 1:
+        if opts.mode >= 1:
             geo_packed(W), geo_cheb_packed(W), geo_dcT(W), geo_dcT16(W)  # lazily built weight images: finish them before the streams fork
             _ensure_w16(W)
         return rest(prepare(0, B, side_key=0), 0, B, 0)
     main = torch.cuda.current_stream()
-    if _lib.load().sam6d_get_matmul_mode() >= 1:
+    if opts.mode >= 1:
         geo_packed(W), geo_cheb_packed(W), geo_dcT(W), geo_dcT16(W)  # lazily built weight images: finish them before the streams fork
         _ensure_w16(W)
     per = (B + mb - 1) // mb

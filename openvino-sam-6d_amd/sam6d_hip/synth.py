@@ -116,6 +116,33 @@ def config2_inputs(B=32, seed=1, n_dense=2048, n_model=1024):
                 model=model, rand=rand)
 
 
+def config4_inputs(B=200, n_obj=8, seed=4, n_dense=2048, n_model=1024):
+    """an LM-O-style scene -- B proposals of n_obj objects (object of proposal b: b % n_obj, i.e. ~B / n_obj each),
+    from the config-2 generator.  Template-side tensors are returned UNIQUE, one per object -- dense_po (n_obj,N,3), dense_fo
+    (n_obj,N,256), model_obj (n_obj,P,3) -- with template_ids (B,) int64; `model` (B,P,3) is the per-proposal CAD sample the reference's
+    caller passes (PEM/run_inference_custom_pytorch.py:447-454).  repeated(d) gives the per-instance repeated form."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g) - 0.5
+    dense_pm = u(B, n_dense, 3) + torch.tensor([0.0, 0.0, 8.0])
+    dense_fm = torch.randn(B, n_dense, C, generator=g)
+    dense_po = u(n_obj, n_dense, 3)
+    dense_fo = torch.randn(n_obj, n_dense, C, generator=g)
+    model_obj = u(n_obj, n_model, 3)
+    ids = torch.arange(B, dtype=torch.int64) % n_obj
+    rand = torch.rand(B, 18000, generator=g)
+    return dict(dense_pm=dense_pm, dense_fm=dense_fm, dense_po=dense_po, dense_fo=dense_fo, radius=torch.ones(B), model=model_obj[ids].contiguous(),
+                rand=rand, template_ids=ids)
+
+
+def repeated(d):
+    """The per-instance repeated form of a config4_inputs dict (what the reference's caller builds with .repeat / indexing)."""
+    ids = d["template_ids"].to(d["dense_po"].device)
+    out = {k: v for k, v in d.items() if k != "template_ids"}
+    out["dense_po"] = d["dense_po"][ids].contiguous()
+    out["dense_fo"] = d["dense_fo"][ids].contiguous()
+    return out
+
+
 def config3_inputs(seed=0, Nq=200, Nt=42, D=1024, Pn=256, H=480, W=640):
     """SURVEY 8d config 3 (ISM template scoring): 200 proposals x 42 templates, 1024-d class tokens, 256 x 1024 patch descriptors with
     30 % of the patches masked out, box masks on a 480 x 640 depth image, 2048 CAD points, 42 template poses; CPU tensors.  Descriptors

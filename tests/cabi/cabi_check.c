@@ -58,6 +58,10 @@ int main(void) {
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
   printf("cabi_check: ABI version %d\n", sam6d_abi_version());
+  if (sam6d_abi_version() != SAM6D_ABI_VERSION) {
+    fprintf(stderr, "library ABI %d != header ABI %d\n", sam6d_abi_version(), SAM6D_ABI_VERSION);
+    return 3;
+  }
 
   /* ---- clouds: B = 2, N = 5000 (> 4096: the multi-workgroup FPS with its scratch row), 256 samples */
   const int B = 2, N = 5000, M = 256, NS = 32, C = 5;

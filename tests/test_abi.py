@@ -20,10 +20,12 @@ def test_header_symbols_exported_and_bound():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "symbol %s declared in sam6d_hip.h but not exported" % n
-    bound = set(_lib.SIGNATURES) | {"sam6d_last_error", "sam6d_abi_version", "sam6d_get_matmul_mode"}
+    bound = set(_lib.SIGNATURES) | {"sam6d_last_error", "sam6d_abi_version", "sam6d_get_matmul_mode", "sam6d_get_thread_matmul_mode"}
     assert set(names) == bound, (set(names) ^ bound)
     _lib.load()
-    assert _lib.load().sam6d_abi_version() >= 1
+    hdr = open(os.path.join(ROOT, "include", "sam6d_hip.h")).read()
+    ver = int(re.search(r"#define\s+SAM6D_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert _lib.load().sam6d_abi_version() == ver == _lib.ABI_VERSION, "header, library and Python binding disagree on the ABI version"
 
 
 def test_every_declaration_cites_the_reference():
@@ -32,7 +34,7 @@ def test_every_declaration_cites_the_reference():
     blocks = re.findall(r"/\*((?:(?!\*/).)*?)\*/\s*int\s+(sam6d_[a-z0-9_]+)\s*\(", txt, flags=re.S)
     assert blocks
     for comment, name in blocks:
-        if name in ("sam6d_abi_version", "sam6d_get_matmul_mode"):
+        if name in ("sam6d_abi_version", "sam6d_get_matmul_mode", "sam6d_get_thread_matmul_mode", "sam6d_set_thread_matmul_mode"):
             continue
         assert re.search(r"\.(cpp|py|h):\d+", comment), "%s: no reference file:line in its comment" % name
 

@@ -362,7 +362,7 @@ def test_config5_fp16_single_product_mode(dev, sd):
     res = {}
     try:
         for mode in (1, 2):
-            _lib.call("sam6d_set_matmul_mode", mode)
+            _lib.call("sam6d_set_thread_matmul_mode", mode)
             out = torch.empty(900, 256, device=dev)
             pem.gemm(A, Wt, None, out, 900, 256, 256, 256, 256, 256)
             gerr = float((out.cpu().double() - want).abs().max()) / float(want.abs().max())
@@ -371,7 +371,7 @@ def test_config5_fp16_single_product_mode(dev, sd):
             torch.cuda.synchronize()
             res[mode] = (gerr, R.cpu(), t.cpu(), s.cpu(), Rb.cpu(), tb.cpu(), sb.cpu())
     finally:
-        _lib.call("sam6d_set_matmul_mode", prev)
+        _lib.call("sam6d_set_thread_matmul_mode", -1)
     g1 = res[1][0]
     g2, R2, t2, s2, Rb2, tb2, sb2 = res[2]
     dR = float((R2 - _t(gold["kat_R"])).abs().max()); dt = float((t2 - _t(gold["kat_t"])).abs().max())
@@ -389,3 +389,60 @@ def test_config5_fp16_single_product_mode(dev, sd):
         assert torch.isfinite(Rm).all() and torch.isfinite(tm).all() and torch.isfinite(sm).all()
         assert float((torch.linalg.det(Rm.double()) - 1).abs().max()) < 1e-4
     assert dt < 5e-2 and ds < 1e-1
+
+
+def test_template_ids_multi_object_batch_equals_repeated_form(dev, W):
+    """BASELINE config 4's batch shape: proposals of 8 objects mixed in one batch (PEM/provider/bop_test_dataset.py:107,156 returns an
+    `obj` index per instance).  pem_match(template_ids=...) takes the 8 UNIQUE templates, runs the template-side pose-independent work
+    once per template and must return bit for bit what the per-instance repeated form returns -- 8 objects x 3 proposals here, with an
+    uneven assignment (one object without a proposal, one with five) and the ids out of order; also through the drop-in Net.match."""
+    from sam6d_hip import pem, synth
+    B, T = 24, 8
+    inp = synth.config4_inputs(B=B, n_obj=T, seed=14)
+    ids = inp["template_ids"].clone()
+    ids[ids == 7] = 2          # object 7 has no proposal, object 2 twice as many
+    ids = ids[torch.randperm(B, generator=torch.Generator().manual_seed(3))]
+    inp["template_ids"] = ids
+    inp["model"] = (torch.rand(T, 1024, 3, generator=torch.Generator().manual_seed(5)) - 0.5)[ids].contiguous()
+    d = {k: v.to(dev) for k, v in inp.items()}
+    rep = synth.repeated(d)
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    a = pem.pem_match(*[rep[k] for k in keys], W, rep["rand"])
+    b = pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"])
+    for x, y, what in zip(a, b, ("R", "t", "score")):
+        assert torch.equal(x, y), "%s differs between the repeated form and template_ids: %.3e" % (what, float((x - y).abs().max()))
+    # without the side stream (the static fine work inline) and with aux
+    c = pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"], cfg=dict(pem.DEFAULT_CFG, overlap=False))
+    e = pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"], return_aux=True)
+    for x, y, z in zip(a, c, e):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    with pytest.raises(ValueError):
+        pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"] + T)
+    with pytest.raises(ValueError):
+        pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"][:-1])
+
+
+def test_config4_200_proposals_8_objects_template_ids(dev, W):
+    """Config 4 at full size on one GPU: 200 proposals of 8 objects in ONE call with template_ids; equal (bitwise) to the same scene run
+    as 8 round-robin shards with their own template_ids (what 8 ranks would compute), and to the repeated form on a 25-proposal shard."""
+    from sam6d_hip import pem, synth
+    from sam6d_hip.parallel import shard_indices
+    inp = synth.config4_inputs(B=200, n_obj=8, seed=4)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    whole = pem.pem_match(*[d[k] for k in keys], W, d["rand"], template_ids=d["template_ids"])
+    assert all(torch.isfinite(x).all() for x in whole)
+    R = torch.empty_like(whole[0]); t = torch.empty_like(whole[1]); s = torch.empty_like(whole[2])
+    for r in range(8):
+        sl = shard_indices(200, r, 8)[0].to(dev)
+        part = pem.pem_match(d["dense_pm"][sl].contiguous(), d["dense_fm"][sl].contiguous(), d["dense_po"], d["dense_fo"],
+                             d["radius"][sl].contiguous(), d["model"][sl].contiguous(), W, d["rand"][sl].contiguous(),
+                             template_ids=d["template_ids"][sl])
+        R[sl], t[sl], s[sl] = part
+        if r == 3:
+            rep = pem.pem_match(d["dense_pm"][sl].contiguous(), d["dense_fm"][sl].contiguous(),
+                                d["dense_po"][d["template_ids"][sl]].contiguous(), d["dense_fo"][d["template_ids"][sl]].contiguous(),
+                                d["radius"][sl].contiguous(), d["model"][sl].contiguous(), W, d["rand"][sl].contiguous())
+            for x, y in zip(part, rep):
+                assert torch.equal(x, y)
+    assert torch.equal(R, whole[0]) and torch.equal(t, whole[1]) and torch.equal(s, whole[2])

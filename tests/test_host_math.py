@@ -54,3 +54,35 @@ def test_chebyshev_range_covers_normalised_clouds():
     for k in ("dense_pm", "dense_po"):
         p = inp[k]
         assert float(torch.cdist(p, p).amax()) / 0.2 < pem.GEO_XMAX
+
+
+def test_options_object_resolves_env_and_gates_routes(monkeypatch):
+    """pem.Options: the explicit replacement of the process-global matmul mode + SAM6D_* switches.  Environment switches resolve into it
+    once; routes that exist only in the split-precision arithmetic are gated by the mode; the thread-local mode of the library follows
+    an explicit override and falls back to the process default."""
+    from sam6d_hip import _lib
+    lib = _lib.load()
+    assert lib.sam6d_get_thread_matmul_mode() == -1
+    base = lib.sam6d_get_matmul_mode()
+    o = pem.Options()
+    assert o.mode == base and o.fused_block == (base >= 1) and o.microbatch == 1 and o.rpe_products == 0
+    monkeypatch.setenv("SAM6D_FUSED_BLOCK", "0")
+    monkeypatch.setenv("SAM6D_RPE_PRODUCTS", "3")
+    monkeypatch.setenv("SAM6D_MICROBATCH", "2")
+    e = pem.Options.from_env()
+    assert not e.fused_block and not e.fused_front and not e.rows_linear and e.rpe_products == 3 and e.microbatch == 2
+    assert pem.Options.from_env(fused_block=True).fused_block == (base >= 1)
+    x = pem.Options(matmul_mode=0)
+    assert x.mode == 0 and not (x.w16 or x.fused_block or x.fused_rpe or x.fused_out)
+    assert x.replace(matmul_mode=1).mode == 1
+    try:
+        pem.Options(no_such_switch=1)
+        assert False, "unknown field accepted"
+    except TypeError:
+        pass
+    # thread override: visible through sam6d_get_matmul_mode, gone after -1
+    assert lib.sam6d_set_thread_matmul_mode(0) == 0
+    assert lib.sam6d_get_matmul_mode() == 0 and pem.Options().mode == 0
+    assert lib.sam6d_set_thread_matmul_mode(-1) == 0
+    assert lib.sam6d_get_matmul_mode() == base
+    assert lib.sam6d_set_thread_matmul_mode(7) != 0

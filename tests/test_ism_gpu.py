@@ -157,3 +157,20 @@ def test_empty_selection(dev):
     s = torch.zeros(10, 1, 42, device=dev)
     sel, obj, sem, best = ism.semantic_select(s, "avg_5", 0.2)
     assert sel.numel() == 0 and obj.numel() == 0 and sem.numel() == 0 and best.numel() == 0
+
+
+def test_trimesh_utils_dropin_translation_one_launch(dev, ism_model):
+    """The stand-alone drop-in utils.trimesh_utils.depth_image_to_pointcloud_translate_torch (ISM/utils/trimesh_utils.py:77-105) on ALL
+    masked depth maps in one launch (round 3 looped over the proposals in Python and built an (N,H,W) ones tensor): equal to the
+    reference's captured translation bit for bit, with the reference caller's dtypes (mask * int32 depth, float64 K / depth_scale)."""
+    tu = importlib.import_module("utils.trimesh_utils")
+    g = golden("ism")
+    d = ism_inputs(int(g["seed"]))
+    masks, _ = ism_masks(d["gen"], len(g["sel"]))
+    masked = masks.to(dev) * d["depth"][None].to(dev)  # detector.py:243
+    tr = tu.depth_image_to_pointcloud_translate_torch(masked, d["depth_scale"].to(dev), d["K"].to(dev))
+    assert tr.shape == (len(g["sel"]), 3)
+    assert np.array_equal(tr.to(torch.float32).cpu().numpy(), g["translate"])
+    # an empty mask: the reference's sum / (0 + 1e-8) = 0
+    z = tu.depth_image_to_pointcloud_translate_torch(torch.zeros(2, 48, 64, device=dev), 1.0, d["K"].to(dev))
+    assert float(z.abs().max()) == 0.0

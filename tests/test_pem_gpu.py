@@ -218,10 +218,10 @@ def test_pe_mlp_max_register_chained_vs_exact_and_fp64(dev, W, B, N, S):
 
     got = run()
     try:
-        _lib.call("sam6d_set_matmul_mode", 0)
+        _lib.call("sam6d_set_thread_matmul_mode", 0)
         exact = run()
     finally:
-        _lib.call("sam6d_set_matmul_mode", 1)
+        _lib.call("sam6d_set_thread_matmul_mode", -1)
     assert float((got[:, :128] + 7.0).abs().max()) == 0.0, "columns outside [off, off+128) were touched"
     if B * N * S <= 4_000_000:
         nb = torch.gather(pts.double()[:, None].expand(B, N, N, 3), 2, idx.long()[..., None].expand(B, N, S, 3))
@@ -361,6 +361,50 @@ def test_select_smallest_is_the_stable_rank_order(dev, B, n, k):
     torch.cuda.synchronize()
     want = torch.sort(d, dim=1, stable=True)[1][:, :k].to(torch.int32)
     assert torch.equal(sel.cpu(), want)
+
+
+@pytest.mark.parametrize("n,k", [(14000, 150), (14318, 1), (14319, 1), (14400, 300), (15000, 300)])
+def test_select_smallest_long_rows(dev, n, k):
+    """Rows around the LDS limit of the radix select ((n + 2k) * 4 bytes + its 8 KB histogram must fit 64 KB): below it the radix kernel,
+    above it the all-pairs kernel, same stable rank order either way (the old guard let 60 000 dynamic bytes through)."""
+    from sam6d_hip import _lib, pem
+    gen = torch.Generator().manual_seed(n)
+    d = torch.rand(2, n, generator=gen)
+    d[:, ::5] = d[:, 1:2].clone()
+    sel = torch.full((2, k), -1, dtype=torch.int32, device=dev)
+    dd = d.to(dev)
+    _lib.call("sam6d_select_smallest", dd.data_ptr(), 2, n, k, sel.data_ptr(), pem._s())
+    torch.cuda.synchronize()
+    assert torch.equal(sel.cpu(), torch.sort(d, dim=1, stable=True)[1][:, :k].to(torch.int32))
+
+
+@pytest.mark.parametrize("P", [3277, 4096, 4097])
+def test_coarse_rt_large_model_cloud(dev, P):
+    """CAD clouds of 3277 .. 4096 points need more than the default 64 KB of dynamic LDS in the matrix-core scoring kernel (the
+    attribute was never raised and the launch failed); 4097 takes the vector-ALU kernel.  The score of every selected hypothesis must
+    equal the vector-ALU kernel's bit for bit (same fma chain) and the pose the oracle's."""
+    from sam6d_hip import _lib, pem
+    from oracle import pem_oracle as O
+    g = golden("coarse_rt")
+    p1, p2, u = (_t(g[k]) for k in ("p1", "p2", "u"))
+    gen = torch.Generator().manual_seed(P)
+    extra = torch.rand(2, P - 1024, 3, generator=gen) - 0.5
+    model = torch.cat([_t(g["model"]), extra], 1).contiguous()
+    att = _t(g["att"])
+    radius = torch.ones(2, device=dev)
+    R, t, aux = pem.compute_coarse_Rt(att.to(dev), p1.to(dev), p2.to(dev), model.to(dev), radius, u.to(dev), return_aux=True)
+    Ro, to = O.compute_coarse_Rt(att, p1, p2, model, u)[:2]
+    _close(R, Ro, 1e-4, "coarse R, P = %d" % P); _close(t, to, 1e-4, "coarse t, P = %d" % P)
+    # the plain kernel on the same selection
+    sc = torch.empty_like(aux["scores"]); Rb = torch.empty(2, 3, 3, device=dev); tb = torch.empty(2, 3, device=dev)
+    best = torch.empty(2, dtype=torch.int32, device=dev)
+    md, p1d = model.to(dev), p1.to(dev)
+    _lib.call("sam6d_score_select_hypotheses", aux["top"].data_ptr(), aux["Rs"].data_ptr(), aux["ts"].data_ptr(), p1d.data_ptr(),
+              aux["w1"].data_ptr(), md.data_ptr(), radius.data_ptr(), 2, 196, P, 6000, 300, sc.data_ptr(), Rb.data_ptr(), tb.data_ptr(),
+              best.data_ptr(), pem._s())
+    torch.cuda.synchronize()
+    assert torch.equal(sc.cpu(), aux["scores"].cpu()), "matrix-core and vector-ALU hypothesis scores differ"
+    assert torch.equal(best.cpu(), aux["best"].cpu())
 
 
 def test_cumsum_norm_and_sampling_vs_float64(dev):
@@ -565,12 +609,12 @@ def test_matmul_modes_error_vs_fp64(dev):
     prev = _lib.load().sam6d_get_matmul_mode()
     try:
         for mode in (0, 1):
-            _lib.call("sam6d_set_matmul_mode", mode)
+            _lib.call("sam6d_set_thread_matmul_mode", mode)
             out = torch.empty(M, N, device=dev)
             pem.gemm(Ad, Wd, None, out, M, N, K, K, K, N)
             errs[mode] = float((out.cpu().double() - want).abs().max())
     finally:
-        _lib.call("sam6d_set_matmul_mode", prev)
+        _lib.call("sam6d_set_thread_matmul_mode", -1)
     scale = float(want.abs().max())
     print("\nmatmul max abs err vs fp64: exact-fp32 %.2e, fp16x3 %.2e (result scale %.1f)" % (errs[0], errs[1], scale))
     assert errs[0] < 2e-6 * scale and errs[1] < 4e-6 * scale
@@ -586,10 +630,10 @@ def test_geo_embedding_large_index_fallback(dev, W, sd):
     got = pem.geo_embedding(pts.to(dev), W)
     prev = _lib.load().sam6d_get_matmul_mode()
     try:
-        _lib.call("sam6d_set_matmul_mode", 0)
+        _lib.call("sam6d_set_thread_matmul_mode", 0)
         exact = pem.geo_embedding(pts.to(dev), W)
     finally:
-        _lib.call("sam6d_set_matmul_mode", prev)
+        _lib.call("sam6d_set_thread_matmul_mode", -1)
     assert torch.equal(got, exact), "flagged call must be produced by the exact kernel"
     want = O.geo_embedding(pts, sd)
     # arguments ~1e5: one fp32 ulp of the index (0.03) already moves sin/cos by O(1e-2); compare loosely
@@ -613,10 +657,10 @@ def test_geo_embedding_chebyshev_vs_sinusoid_kernels(dev, W, sd, spread):
     pts[1, 5] = pts[1, 6]  # duplicate point: d = 0, degenerate angles
     got = pem.geo_embedding(pts.to(dev), W).cpu()
     try:
-        _lib.call("sam6d_set_matmul_mode", 0)
+        _lib.call("sam6d_set_thread_matmul_mode", 0)
         exact = pem.geo_embedding(pts.to(dev), W).cpu()
     finally:
-        _lib.call("sam6d_set_matmul_mode", 1)
+        _lib.call("sam6d_set_thread_matmul_mode", -1)
     d = float((got - exact).abs().max())
     scale = float(exact.abs().max())
     print("\nchebyshev vs exact-fp32 kernel, spread %.1f: max abs diff %.2e (scale %.1f)" % (spread, d, scale))
@@ -768,10 +812,10 @@ def test_rpe_fused_range_guard(dev, sd):
                 pem.geo_context(pts, W2)
         got = pem.geo_embedding(pts, W2)
         try:
-            _lib.call("sam6d_set_matmul_mode", 0)
+            _lib.call("sam6d_set_thread_matmul_mode", 0)
             want = pem.geo_embedding(pts, W2)
         finally:
-            _lib.call("sam6d_set_matmul_mode", prev)
+            _lib.call("sam6d_set_thread_matmul_mode", -1)
         assert torch.isfinite(got).all(), "scale %g: non-finite embedding (fp16 image overflow)" % scale
         sc = float(want.abs().max())
         err = float((got - want).abs().max())
@@ -791,17 +835,37 @@ def test_pem_match_fused_vs_materialised(dev, W):
         cfg = dict(pem.DEFAULT_CFG, fused_rpe=fused)
         outs.append([o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
                                                     d["model"], W, d["rand"], cfg=cfg)])
-    try:
-        _lib.call("sam6d_set_matmul_mode", 0)
-        exact = [o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
-                                                d["model"], W, d["rand"])]
-    finally:
-        _lib.call("sam6d_set_matmul_mode", 1)
+    # the exact-fp32 arithmetic as an explicit per-call option (no process-global switch is touched)
+    exact = [o.cpu() for o in pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"],
+                                            d["model"], W, d["rand"], options=pem.Options(matmul_mode=0))]
+    assert _lib.load().sam6d_get_matmul_mode() == 1 and _lib.load().sam6d_get_thread_matmul_mode() == -1
     for a, b, e, what in zip(outs[0], outs[1], exact, ("R", "t", "score")):
         print("\n%s: fused-vs-exact %.2e  materialised-vs-exact %.2e" % (what, float((a - e).abs().max()), float((b - e).abs().max())))
     for a, b, e, what in zip(outs[0], outs[1], exact, ("R", "t", "score")):
         _close(a, e, 1e-4, "pem_match fused vs exact-fp32 mode: " + what)
         _close(b, e, 1e-4, "pem_match materialised (Chebyshev) vs exact-fp32 mode: " + what)
+
+
+def test_two_weight_sets_with_different_arithmetic_in_one_process(dev, sd):
+    """matmul mode and kernel routes travel with the weight set (PemWeights(..., options=...)), not with the process: a split-precision
+    model and an exact-fp32 model interleaved call by call give what each gives alone (bitwise), and differ from each other."""
+    from sam6d_hip import _lib, pem, synth
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("needs the default (fp16x3) process mode")
+    inp = synth.config2_inputs(B=2, seed=21)
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    args = [d[k] for k in ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")]
+    Wa = pem.PemWeights(sd, dev, options=pem.Options(matmul_mode=1))
+    Wb = pem.PemWeights(sd, dev, options=pem.Options(matmul_mode=0))
+    run = lambda Wx: [o.cpu() for o in pem.pem_match(*args, Wx, d["rand"])]
+    a0, b0 = run(Wa), run(Wb)
+    b1, a1 = run(Wb), run(Wa)
+    for x, y in zip(a0 + b0, a1 + b1):
+        assert torch.equal(x, y)
+    assert any(not torch.equal(x, y) for x, y in zip(a0, b0)), "the two arithmetic modes cannot be bit-identical"
+    for x, y, what in zip(a0, b0, ("R", "t", "score")):
+        _close(x, y, 1e-4, "split vs exact arithmetic: " + what)
+    assert _lib.load().sam6d_get_thread_matmul_mode() == -1
 
 
 def test_pem_match_repeatable_with_side_stream(dev, W):
