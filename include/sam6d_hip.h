@@ -428,6 +428,17 @@ int sam6d_ism_patch_fused_scores(const void* ws, int Ns, int P, float thred, flo
 int sam6d_ism_project(const float* masks, const int* depth, const double* K, double depth_scale, const float* poses,
                       const float* pointcloud, const int* best, const int* obj, int Ns, int H, int W, int Npc,
                       double* part_ws, int* image_vu, int* xyxy, float* translate, void* stream);
+/* sam6d_ism_project with the masks read IN PLACE as a 16-byte-per-lane stream (same call sites: ISM/model/detector.py:209-246,
+ * ISM/utils/trimesh_utils.py:77-105): masks (Nq,H,W) with mask_bytes = 1 (uint8 / bool, non-zero = inside: SAM's binary proposals) or
+ * 4 (float32, as Detections.masks holds them, ISM/model/utils.py:80-95); mask_index (Ns) i64 or NULL: proposal i uses mask
+ * mask_index[i] -- the class-token selection of detector.py:289-296 applied without the gathered (Ns,H,W) copy Detections.filter makes.
+ * The masked-depth sums are exact integer sums in float64 and the divisions by fx / fy happen once per proposal.  The fast path needs
+ * W % 16 == 0, depth_scale > 0 and 16-byte aligned masks / depth; otherwise float32 masks without an index fall back to
+ * sam6d_ism_project.  part_ws: sam6d_ism_project_workspace_doubles(Ns, H, W) doubles. */
+size_t sam6d_ism_project_workspace_doubles(int Ns, int H, int W);
+int sam6d_ism_project2(const void* masks, int mask_bytes, const long long* mask_index, const int* depth, const double* K,
+                       double depth_scale, const float* poses, const float* pointcloud, const int* best, const int* obj, int Ns, int H,
+                       int W, int Npc, double* part_ws, int* image_vu, int* xyxy, float* translate, void* stream);
 
 /* replaces depth_image_to_pointcloud_translate_torch(depth, scale, K) itself (ISM/utils/trimesh_utils.py:77-105) for a direct caller:
  * masked_depth (N,H,W) f32 = N already-masked depth maps (mm), K (3,3) f64 row-major, -> translate (N,3) f32 = the mean back-projected

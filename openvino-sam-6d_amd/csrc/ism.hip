@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void ism_project_kernel(const double* __restri
                                                           const float* __restrict__ pc, const int* __restrict__ best,
                                                           const int* __restrict__ obj, const double* __restrict__ Kd, int Npc, int H,
                                                           int Wd, int* __restrict__ vu, int* __restrict__ xyxy,
-                                                          float* __restrict__ translate) {
+                                                          float* __restrict__ translate, int nch = ISM_TCH, double zscale = 0.0) {
   __shared__ float tr[3];
   float K[9];
 #pragma unroll
@@ -469,12 +469,24 @@ __global__ __launch_bounds__(256) void ism_project_kernel(const double* __restri
   __shared__ int bb[4][4];
   const int i = blockIdx.x, t = threadIdx.x;
   if (t < 3) {
-    double s = 0, n = 0;
-    for (int c = 0; c < ISM_TCH; ++c) {
-      s += part[((size_t)i * ISM_TCH + c) * 4 + t];
-      n += part[((size_t)i * ISM_TCH + c) * 4 + 3];
+    if (zscale == 0.0) {  // partials = sums of the per-pixel coordinates (ism_translate_partial_kernel)
+      double s = 0, n = 0;
+      for (int c = 0; c < nch; ++c) {
+        s += part[((size_t)i * nch + c) * 4 + t];
+        n += part[((size_t)i * nch + c) * 4 + 3];
+      }
+      tr[t] = (float)(s / (n + 1e-8));
+    } else {
+      // partials = (sum u md, sum v md, sum md, count) of the masked depth md (ism_translate_fast_kernel; exact: integers below 2^53):
+      // sum_p (u - cx) Z / fx with Z = md zscale  =  (sum u md - cx sum md) zscale / fx
+      double su = 0, sv = 0, sm = 0, n = 0;
+      for (int c = 0; c < nch; ++c) {
+        const double* q = part + ((size_t)i * nch + c) * 4;
+        su += q[0]; sv += q[1]; sm += q[2]; n += q[3];
+      }
+      const double v = t == 0 ? (su - Kd[2] * sm) * zscale / Kd[0] : t == 1 ? (sv - Kd[5] * sm) * zscale / Kd[4] : sm * zscale;
+      tr[t] = (float)(v / (n + 1e-8));
     }
-    tr[t] = (float)(s / (n + 1e-8));
     translate[i * 3 + t] = tr[t];
   }
   __syncthreads();
@@ -511,6 +523,109 @@ __global__ __launch_bounds__(256) void ism_project_kernel(const double* __restri
     xyxy[i * 4 + 2] = max(max(bb[2][0], bb[2][1]), max(bb[2][2], bb[2][3]));
     xyxy[i * 4 + 3] = max(max(bb[3][0], bb[3][1]), max(bb[3][2], bb[3][3]));
   }
+}
+
+// Round 4: the masked-depth sums as a 16-byte-per-lane stream.  The old kernel read 4-byte mask floats and did three fp64 divisions per
+// pixel (0.2 ms for 246 MB: 1.2 TB/s).  Here a workgroup owns a chunk of 4096 pixels (16 per lane) of ISM_PG consecutive proposals: the
+// depth chunk is loaded once into registers, every proposal costs one 16-byte mask load per lane (uint8 masks: 16 pixels; fp32 masks:
+// four float4 loads), and the per-pixel work is a select, one fp64 add and one fp64 fma -- the divisions move to the finish
+// (sum_p (u - cx) Z_p / fx = (sum u md - cx sum md) zscale / fx with exact integer sums).  Masks are read in place through an
+// optional index (the proposals selected by the class-token filter: no gathered (Ns,H,W) copy).  Needs W % 16 == 0 (a lane's 16
+// pixels share an image row) and 16-byte aligned rows; depth_scale > 0.
+#define ISM_PG 8
+template <typename MT>
+__global__ __launch_bounds__(256) void ism_translate_fast_kernel(const MT* __restrict__ masks, const long long* __restrict__ midx,
+                                                                 const int* __restrict__ depth, int Ns, long npx, int Wd, int nch,
+                                                                 double* __restrict__ part) {
+  __shared__ double red[4][4];
+  const int ch = blockIdx.x, g0 = blockIdx.y * ISM_PG, t = threadIdx.x;
+  const long p0 = (long)ch * 4096 + (long)t * 16;
+  const bool inb = p0 < npx;  // (npx % 16 == 0: a lane's 16 pixels are all inside or all outside)
+  float dz[16];
+  {
+    const uint4* dp = reinterpret_cast<const uint4*>(depth + (inb ? p0 : 0));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = dp[q];
+      dz[4 * q] = (float)(int)v.x; dz[4 * q + 1] = (float)(int)v.y; dz[4 * q + 2] = (float)(int)v.z; dz[4 * q + 3] = (float)(int)v.w;
+    }
+  }
+  const int u0 = (int)(p0 % Wd), v0 = (int)(p0 / Wd);
+  for (int gi = 0; gi < ISM_PG; ++gi) {
+    const int i = g0 + gi;
+    if (i >= Ns) break;  // (block-uniform)
+    const MT* m = masks + (size_t)(midx ? midx[i] : i) * npx + (inb ? p0 : 0);
+    float mk[16];
+    if constexpr (sizeof(MT) == 1) {
+      typedef unsigned ism_u4 __attribute__((ext_vector_type(4)));
+      const ism_u4 w = __builtin_nontemporal_load(reinterpret_cast<const ism_u4*>(m));
+      const unsigned ww[4] = {w[0], w[1], w[2], w[3]};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mk[j] = ((ww[j >> 2] >> (8 * (j & 3))) & 0xffu) ? 1.0f : 0.0f;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        typedef float ism_f4 __attribute__((ext_vector_type(4)));
+        const ism_f4 w = __builtin_nontemporal_load(reinterpret_cast<const ism_f4*>(m) + q);
+        mk[4 * q] = w[0]; mk[4 * q + 1] = w[1]; mk[4 * q + 2] = w[2]; mk[4 * q + 3] = w[3];
+      }
+    }
+    double sm = 0.0, sj = 0.0;
+    float cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float mdf = mk[j] * dz[j];  // mask * depth as the reference forms it (fp32 product; exact for 0/1 masks, depth < 2^24)
+      const bool ok = inb && mdf > 0.f; // Z = md * zscale > 0 with zscale > 0
+      const double md = ok ? (double)mdf : 0.0;
+      sm += md;
+      sj = fma((double)j, md, sj);
+      cnt += ok ? 1.f : 0.f;
+    }
+    double su = fma((double)u0, sm, sj), sv = (double)v0 * sm, sn = (double)cnt;
+    su = wave_sum(su); sv = wave_sum(sv); sm = wave_sum(sm); sn = wave_sum(sn);
+    if (gi) __syncthreads();
+    if ((t & 63) == 0) { red[0][t >> 6] = su; red[1][t >> 6] = sv; red[2][t >> 6] = sm; red[3][t >> 6] = sn; }
+    __syncthreads();
+    if (t < 4) part[((size_t)i * nch + ch) * 4 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+  }
+}
+
+extern "C" size_t sam6d_ism_project_workspace_doubles(int Ns, int H, int W) {
+  const long npx = (long)H * W;
+  const long nch = (npx + 4095) / 4096;
+  return (size_t)Ns * (size_t)(nch > ISM_TCH ? nch : ISM_TCH) * 4;
+}
+
+extern "C" int sam6d_ism_project2(const void* masks, int mask_bytes, const long long* mask_index, const int* depth, const double* K,
+                                  double depth_scale, const float* poses, const float* pointcloud, const int* best, const int* obj,
+                                  int Ns, int H, int W, int Npc, double* part_ws, int* image_vu, int* xyxy, float* translate,
+                                  void* stream) {
+  SAM6D_REQUIRE(masks && depth && K && poses && pointcloud && best && obj && part_ws && image_vu && xyxy && translate,
+                "ism_project2: null pointer");
+  SAM6D_REQUIRE(mask_bytes == 1 || mask_bytes == 4, "ism_project2: masks must be uint8 / bool (1 byte) or float32 (4 bytes) per pixel");
+  SAM6D_REQUIRE(Ns >= 0 && Ns <= 65535 * ISM_PG && H > 0 && W > 0 && Npc > 0, "ism_project2: bad sizes");
+  if (Ns == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const long npx = (long)H * W;
+  const bool fast = (W % 16) == 0 && depth_scale > 0.0 && ((((size_t)masks) | ((size_t)depth)) & 15) == 0;
+  if (!fast) {
+    SAM6D_REQUIRE(mask_bytes == 4 && !mask_index,
+                  "ism_project2: the 16-byte path needs W %% 16 == 0, depth_scale > 0 and 16-byte aligned buffers; the general path "
+                  "(sam6d_ism_project) takes float32 masks without an index");
+    return sam6d_ism_project((const float*)masks, depth, K, depth_scale, poses, pointcloud, best, obj, Ns, H, W, Npc, part_ws, image_vu,
+                             xyxy, translate, stream);
+  }
+  const int nch = (int)((npx + 4095) / 4096);
+  const dim3 grid(nch, (Ns + ISM_PG - 1) / ISM_PG);
+  if (mask_bytes == 1)
+    hipLaunchKernelGGL(ism_translate_fast_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char*)masks, mask_index, depth, Ns,
+                       npx, W, nch, part_ws);
+  else
+    hipLaunchKernelGGL(ism_translate_fast_kernel<float>, grid, dim3(256), 0, s, (const float*)masks, mask_index, depth, Ns, npx, W, nch,
+                       part_ws);
+  hipLaunchKernelGGL(ism_project_kernel, dim3(Ns), dim3(256), 0, s, part_ws, poses, pointcloud, best, obj, K, Npc, H, W, image_vu, xyxy,
+                     translate, nch, depth_scale / 1000.0);
+  SAM6D_LAUNCH_CHECK("ism_project2");
 }
 
 extern "C" int sam6d_ism_project(const float* masks, const int* depth, const double* K, double depth_scale, const float* poses,

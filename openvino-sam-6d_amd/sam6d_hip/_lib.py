@@ -80,6 +80,8 @@ SIGNATURES = {
     "sam6d_ism_patch_fused": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, ctypes.c_size_t, c_p],
     "sam6d_ism_patch_fused_scores": [c_p, c_i, c_i, c_f, c_p, c_p, c_p],
     "sam6d_ism_project": [c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    "sam6d_ism_project_workspace_doubles": [c_i, c_i, c_i],
+    "sam6d_ism_project2": [c_p, c_i, c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "sam6d_ism_translate_maps": [c_p, c_p, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
@@ -147,7 +149,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
-        fn.restype = (c_l if "image_bytes" in name else ctypes.c_size_t) if (name.endswith("_bytes") or name.endswith("_bytes_n")) else c_i
+        fn.restype = (c_l if "image_bytes" in name else ctypes.c_size_t) if name.endswith(("_bytes", "_bytes_n", "_doubles")) else c_i
     mode = os.environ.get("SAM6D_MATMUL_MODE")  # 0 = exact fp32 MFMA, 1 = fp16x3 split (library default)
     if mode is not None:
         if lib.sam6d_set_matmul_mode(int(mode)) != 0:

@@ -104,23 +104,47 @@ def patch_scores_fused(q_appe, ref_appe, pred_obj, best_pose, q_index=None):
 
 
 @on_tensor_device
-def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale):
-    """ISM/model/detector.py:209-246: -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3)."""
-    Ns, H, W = masks.shape
+def project_template_to_image(best_pose, pred_obj, poses, pointcloud, masks, depth, K, depth_scale, mask_index=None):
+    """ISM/model/detector.py:209-246: -> image_vu (Ns,Npc,2) i32, xyxy (Ns,4) i32, translate (Ns,3).
+    masks (Nq,H,W): uint8 / bool (SAM's binary proposals, one byte per pixel) or float32 (Detections.masks), read in place;
+    mask_index (Ns,) i64: proposal i uses masks[mask_index[i]] (the class-token selection without a gathered copy), else Nq == Ns."""
+    Nq, H, W = masks.shape
     Npc = pointcloud.shape[1]
     dev = masks.device
-    masks = masks.to(torch.float32).contiguous()
+    if masks.dtype == torch.bool:
+        masks = masks.view(torch.uint8)
+    elif masks.dtype not in (torch.uint8, torch.float32):
+        masks = masks.to(torch.float32)
+    masks = masks.contiguous()
     depth = depth.to(torch.int32).contiguous()
     Kd = K.to(device=dev, dtype=torch.float64).contiguous()
     best = best_pose.to(torch.int32).contiguous()
     obj = pred_obj.to(torch.int32).contiguous()
-    part = torch.empty(Ns * 64 * 4, dtype=torch.float64, device=dev)
+    Ns = best.shape[0]
+    mi = None
+    if mask_index is not None:
+        mi = mask_index.to(device=dev, dtype=torch.int64).contiguous()
+        if mi.shape[0] != Ns:
+            raise RuntimeError("project_template_to_image: mask_index must have one entry per proposal")
+    elif Nq != Ns:
+        raise RuntimeError("project_template_to_image: %d masks for %d proposals (pass mask_index)" % (Nq, Ns))
     vu = torch.empty(Ns, Npc, 2, dtype=torch.int32, device=dev)
     xyxy = torch.empty(Ns, 4, dtype=torch.int32, device=dev)
     tr = torch.empty(Ns, 3, dtype=torch.float32, device=dev)
-    _lib.call("sam6d_ism_project", _p(masks), _p(depth), Kd.data_ptr(), float(depth_scale), _p(poses.contiguous()),
-              _p(pointcloud.contiguous()), _p(best), _p(obj), Ns, H, W, Npc, part.data_ptr(), vu.data_ptr(), xyxy.data_ptr(),
-              _p(tr), _s())
+    fast = W % 16 == 0 and float(depth_scale) > 0.0
+    if not fast:  # general shapes: float32 masks, gathered
+        masks = masks.to(torch.float32)
+        if mi is not None:
+            masks = take_rows(masks, mi)
+        part = torch.empty(max(Ns, 1) * 64 * 4, dtype=torch.float64, device=dev)
+        _lib.call("sam6d_ism_project", _p(masks), _p(depth), Kd.data_ptr(), float(depth_scale), _p(poses.contiguous()),
+                  _p(pointcloud.contiguous()), _p(best), _p(obj), Ns, H, W, Npc, part.data_ptr(), vu.data_ptr(), xyxy.data_ptr(),
+                  _p(tr), _s())
+        return vu, xyxy, tr
+    part = torch.empty(max(int(_lib.load().sam6d_ism_project_workspace_doubles(Ns, H, W)), 1), dtype=torch.float64, device=dev)
+    _lib.call("sam6d_ism_project2", masks.data_ptr(), masks.element_size(), (mi.data_ptr() if mi is not None else None), _p(depth),
+              Kd.data_ptr(), float(depth_scale), _p(poses.contiguous()), _p(pointcloud.contiguous()), _p(best), _p(obj), Ns, H, W, Npc,
+              part.data_ptr(), vu.data_ptr(), xyxy.data_ptr(), _p(tr), _s())
     return vu, xyxy, tr
 
 

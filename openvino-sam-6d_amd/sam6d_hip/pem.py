@@ -1285,10 +1285,10 @@ def fine_static_a(dp, df, W, cfg, shared_template=False):
     grids that share the chip well).  df: stacked (2B,N,256) or the (scene, template) pair.  shared_template: every proposal carries the SAME template cloud (one object's dense_po /
     dense_fo `.repeat`ed per instance, PEM/run_inference_custom_pytorch.py:445-446): its tokens are computed once, in slot B."""
     if isinstance(shared_template, tuple):
-        # (B, T, gidx): dp = [B scene clouds; T UNIQUE template clouds], df = (scene (B,N,256), template (T,N,256)).  The scene tokens go
+        # (B, T, gidx, ids): dp = [B scene clouds; T UNIQUE template clouds], df = (scene (B,N,256), template (T,N,256)).  The scene tokens go
         # to slots 0 .. B-1 of D (2B slots); the T template token blocks are finished in their own buffer Dt (in_proj here, the PE MLPs
         # in fine_static_b) and then handed to the template slot of every proposal (fine_static_b).
-        B, T, _ = shared_template
+        B, T = shared_template[:2]
         N, K = df[0].shape[1], df[0].shape[2]
         lin = W.fine["in_proj"]
         D = _empty((2 * B, N + 1, C), df[0])
@@ -1326,11 +1326,11 @@ def fine_static_b(dp, D, grp, W, shared_template=False, max_wg=0):
     """Second half: the PE MLPs of the template cloud (persistent workgroups that hold most of every CU's LDS while they run).
     shared_template: one cloud's worth, then the finished token block of slot B is copied to the other template slots."""
     if isinstance(shared_template, tuple):
-        B, T, gidx = shared_template
+        B, T, _, ids = shared_template
         D, Dt = D
         N = dp.shape[1]
         pe_apply(dp[B:], grp, W, Dt, C, (N + 1) * C, max_wg)
-        _lib.call("sam6d_take_rows", Dt.data_ptr(), gidx.data_ptr() + 8 * B, T, B, (N + 1) * C * 4, _p(D, B * (N + 1) * C), _s())
+        _lib.call("sam6d_take_rows", Dt.data_ptr(), ids.data_ptr(), T, B, (N + 1) * C * 4, _p(D, B * (N + 1) * C), _s())
         return D
     Bp, N, _ = dp.shape
     B = Bp // 2
@@ -1476,11 +1476,13 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         if dense_fo.shape[0] != T or template_ids.numel() != B:
             raise ValueError("pem_match: template_ids (B,) indexes dense_po / dense_fo (T, ...)")
         ids = template_ids.to(device=dense_pm.device, dtype=torch.int64).reshape(B)
-        if bool(((ids < 0) | (ids >= T)).any()):  # (one host read-back per call; an out-of-range id would otherwise read a zero block)
+        # one host read-back per call (an out-of-range id would otherwise read a zero block); not while a hipGraph is being captured --
+        # PemGraph validates the ids it is built with on the host
+        if not torch.cuda.is_current_stream_capturing() and bool(((ids < 0) | (ids >= T)).any()):
             raise ValueError("pem_match: template_ids out of range [0, %d)" % T)
         # block b of a stacked (2B, ...) tensor comes from block gidx[b] of the unique (B + T, ...) one
         gidx = torch.cat([torch.arange(B, device=ids.device, dtype=torch.int64), ids + B]).contiguous()
-        tmpl = (B, T, gidx)
+        tmpl = (B, T, gidx, ids.contiguous())
         shared_template = tmpl
         mb = 1
 
@@ -1607,6 +1609,116 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
             src.record_stream(main)
             _lib.call("sam6d_copy_f32", _p(src), _p(dst, lo * w), src.numel(), _s())
     return R, t, sc
+
+
+def describe_paths(W, cfg=DEFAULT_CFG, options=None):
+    """Which kernel routes pem_match takes for THIS weight set: several fast paths are guarded per weight set on the host (the fused RPE
+    score kernel needs proj_a's Chebyshev coefficients inside the fp16 range; its two-product stage 1 needs their tail below 3e-8; the
+    split-precision embedding images need proj_d / proj_a x 1024 finite in fp16) -- with the released checkpoint any of them may route
+    to the slower three-product or materialised kernels.  Returned as a plain dict (bench.py prints it as `paths`)."""
+    o = options if options is not None else (getattr(W, "options", None) or Options.from_env())
+    split = o.mode >= 1
+    img_ok = bool(geo_images_in_range(W)) if split else None
+    sigma_a = cfg.get("sigma_a", 15)
+    fused_ok = bool(fused_rpe_in_range(W, sigma_a)) if split else False
+    fused = bool(cfg.get("fused_rpe", o.fused_rpe)) and split and fused_ok
+    products = None
+    if fused:
+        products = 3 if o.rpe_products == 3 else int(geo_cheb_a_packed(W, sigma_a)[2])
+    return {
+        "matmul_mode": {0: "exact fp32 MFMA", 1: "fp16x3 split", 2: "fp16 single product (experimental)"}[o.mode],
+        "rpe_attention": ("fused score kernel (Chebyshev basis, no embedding tensor), stage 1 = rpe_score_kernel<%d>" % products) if fused
+                         else "materialised embedding + attention_kernel<RPE>",
+        "rpe_stage1_products": products,
+        "fused_rpe_guard_passed": fused_ok if split else None,
+        "embedding_rows": ("geo_cheb_kernel + geo_embed_h3_kernel (split-precision images in range)" if img_ok else
+                           "geo_embed_kernel (exact fp32: weight images leave the fp16 range)") if split else "geo_embed_kernel (exact fp32)",
+        "gemm_route": ("gemm_nt_h3_kernel, pre-split fp16 weight halves" if o.w16 else "gemm_nt_h3_kernel, weights split per tile") if split
+                      else "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)",
+        "layer_tails": "token_block_kernel (one launch per tail)" if o.fused_block else "GEMM + LayerNorm launches",
+        "cross_layers": ("xblock: attention + tail in one launch" if (o.cross_fused and o.xattn_kv) else
+                         "xattn_kernel<kv inside> + token_block_kernel" if o.xattn_kv else "kv GEMM + xattn_kernel + token_block_kernel") if o.fused_block
+                        else "GEMM / attention_kernel launches",
+        "self_attention": "sattn_kernel (q.k^T + softmax + P.v per (cloud, head))" if (o.self_attn and fused) else "batched GEMMs",
+        "fine_match": "finematch.hip pipeline (E written once, read twice)" if (bool(cfg.get("fused_fine", o.fused_fine)) and o.fused_block)
+                      else "materialised (B,N+1,N+1) attention + soft-assignment passes",
+        "fine_out_proj": "out_split_kernel (out_proj + normalize + fp16 split)" if (o.fused_out and split) else "GEMM + fm_prep_kernel",
+        "hypothesis_scoring": "score_hyp_mfma_kernel (fp32 matrix cores)" if o.score_mfma else "score_hyp_kernel (vector ALU)",
+        "ball_query": "cell grid" if o.bq_grid else "all pairs",
+        "overlap_side_stream": bool(cfg.get("overlap", o.overlap)),
+        "microbatch": int(cfg.get("microbatch", o.microbatch)),
+    }
+
+
+class PemGraph:
+    """pem_match captured ONCE into a hipGraph and replayed per step: the ~250 launches of a step (x the number of micro-batch slices)
+    then cost the host one graph launch instead of one ctypes call each.  Two things follow.  Small batches (config 1's single
+    proposal, a strong-scaled shard of 25) stop being bound by the host's launch rate; and the batch can be cut into `microbatch`
+    independent slices whose latency-bound chains (197-token layers, FPS, the pose solver) run BESIDE each other's dense kernels on
+    separate streams of the same graph without any extra host work -- eagerly, the second slice's launches were still being issued
+    while the first slice ran (+2 % only).  Slices are independent proposals: results are bit-identical to the eager call.
+
+    g = PemGraph(W, dense_pm, dense_fm, dense_po, dense_fo, radius, model, rand, microbatch=2)   # example inputs fix the shapes
+    R, t, score = g(dense_pm, dense_fm, dense_po, dense_fo, radius, model, rand)                   # copies into the static inputs, replays
+    R, t, score = g.replay()                                                                      # inputs already written to g.inputs
+
+    The outputs are the graph's static tensors (overwritten by the next replay).  template_ids (fixed at capture) / shared_template
+    as in pem_match.  The reference has no counterpart (eager PyTorch: PEM/run_inference_custom_pytorch.py:447-454 calls the model
+    once per batch)."""
+
+    KEYS = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model", "rand")
+
+    def __init__(self, W, dense_pm, dense_fm, dense_po, dense_fo, radius, model, rand, cfg=DEFAULT_CFG, microbatch=None,
+                 shared_template=False, template_ids=None, options=None, warmup=2):
+        dev = dense_pm.device
+        if dev.type != "cuda":
+            raise RuntimeError("PemGraph: needs HIP device tensors (this build has no CPU path)")
+        self.W = W
+        self.options = options if options is not None else getattr(W, "options", None)
+        self.cfg = dict(cfg)
+        if microbatch is not None:
+            self.cfg["microbatch"] = int(microbatch)
+        self.kw = dict(shared_template=shared_template)
+        if template_ids is not None:
+            T = dense_po.shape[0]
+            ids = template_ids.detach().to("cpu", torch.int64).reshape(-1)
+            if ids.numel() != dense_pm.shape[0] or bool(((ids < 0) | (ids >= T)).any()):
+                raise ValueError("PemGraph: template_ids (B,) must index dense_po / dense_fo (T, ...)")
+            self.kw["template_ids"] = ids.to(dev)
+        if self.options is not None:
+            self.kw["options"] = self.options
+        with torch.cuda.device(dev):
+            self.inputs = {k: v.detach().clone().contiguous() for k, v in zip(self.KEYS, (dense_pm, dense_fm, dense_po, dense_fo, radius,
+                                                                                          model, rand))}
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # eager warm-up on the capture-side stream: weight images, LDS attributes, first-use setup
+                for _ in range(max(1, int(warmup))):
+                    self._call()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = self._call()
+        self.device = dev
+
+    def _call(self):
+        i = self.inputs
+        return pem_match(i["dense_pm"], i["dense_fm"], i["dense_po"], i["dense_fo"], i["radius"], i["model"], self.W, i["rand"],
+                         cfg=self.cfg, **self.kw)
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
+
+    def __call__(self, dense_pm, dense_fm, dense_po, dense_fo, radius, model, rand):
+        for k, v in zip(self.KEYS, (dense_pm, dense_fm, dense_po, dense_fo, radius, model, rand)):
+            dst = self.inputs[k]
+            if v.shape != dst.shape:
+                raise ValueError("PemGraph: %s has shape %s, the graph was captured for %s" % (k, tuple(v.shape), tuple(dst.shape)))
+            if v.data_ptr() != dst.data_ptr():
+                dst.copy_(v, non_blocking=True)
+        return self.replay()
 
 
 def template_is_shared(dense_po, dense_fo):

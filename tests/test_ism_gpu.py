@@ -174,3 +174,82 @@ def test_trimesh_utils_dropin_translation_one_launch(dev, ism_model):
     # an empty mask: the reference's sum / (0 + 1e-8) = 0
     z = tu.depth_image_to_pointcloud_translate_torch(torch.zeros(2, 48, 64, device=dev), 1.0, d["K"].to(dev))
     assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("quirk", [False, True])
+def test_ism_proposals_sharded_equals_unsharded_on_one_gpu(dev, quirk):
+    """SURVEY 8e for the ISM leg through the HIP kernels: the 200 proposals dealt round-robin to 8 shards (what 8 ranks would score),
+    their 12-float records concatenated rank-major (= the all-gather's result) and merged with the device NMS -- the same detections
+    (proposal ids, object ids, boxes, final scores bit for bit) as one unsharded pass; `quirk`: one proposal with a non-positive
+    overlap zeroes the geometric term image-wide, also for proposals of other shards."""
+    from sam6d_hip import ism, parallel
+    d = ism_inputs(0)
+    masks, _ = ism_masks(d["gen"], 200)
+    boxes = torch.tensor([0, 0, 640, 480]).repeat(200, 1)
+    if quirk:
+        boxes[7] = torch.tensor([0, 0, 1, 1])
+    g = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else v) for k, v in d.items()}
+    masks, boxes = masks.to(dev), boxes.to(dev)
+
+    def score_fn(ids):
+        sim = ism.pairwise_similarity(g["q"][ids].contiguous(), g["ref"])
+        sel, obj, sem, best = ism.semantic_select(sim, "avg_5", 0.2)
+        appe, vis = ism.patch_scores_fused(g["q_appe"], g["r_appe"], obj, best, q_index=ids[sel]).scores(0.5)
+        bx = boxes[ids][sel]
+        vu, xyxy, tr = ism.project_template_to_image(best, obj, g["poses"], g["pc"], masks[ids][sel], g["depth"], g["K"], g["depth_scale"])
+        iou = ism.compute_iou(xyxy, bx)
+        return dict(sel=sel, sem=sem, appe=appe, iou=iou, vis=vis, all_positive=torch.is_tensor(iou), object_ids=obj, boxes=bx)
+
+    final_fn = lambda sem, appe, geo, vis: ism.final_score(sem, appe, geo if geo is not None else 0.0, vis)
+    nms_fn = lambda b, s, th, o: ism.nms(b, s, th, object_ids=o)
+    # unsharded
+    r = score_fn(torch.arange(200, device=dev))
+    assert r["all_positive"] == (not quirk)
+    fin = ism.final_score(r["sem"], r["appe"], r["iou"], r["vis"])
+    keep = ism.nms(r["boxes"].float(), fin, 0.25, object_ids=r["object_ids"])
+    want = dict(scores=fin[keep], object_ids=r["object_ids"][keep], boxes=r["boxes"][keep], proposal_ids=r["sel"][keep])
+    assert 0 < len(keep) < len(r["sel"]) < 200
+    # 8 shards, one after the other on this GPU
+    world, recs = 8, []
+    for rank in range(world):
+        ids, nv = parallel.shard_indices(200, rank, world)
+        ids = ids[:nv].to(dev)
+        s = score_fn(ids)
+        recs.append(parallel.pack_detections(s["sem"], s["appe"], s["iou"], s["vis"], s["all_positive"], s["object_ids"], s["boxes"],
+                                             ids[s["sel"]], 25))
+    got = parallel.merge_detections(torch.cat(recs, 0), final_fn, nms_fn, 0.25)
+    for k in ("proposal_ids", "object_ids", "boxes", "scores"):
+        assert torch.equal(got[k].cpu(), want[k].cpu()), "%s differs between the sharded and the unsharded ISM pass" % k
+
+
+def test_project_uint8_masks_read_in_place_through_the_selection(dev):
+    """sam6d_ism_project2: uint8 / bool masks (SAM's binary proposals, one byte per pixel) read in place through the selection index --
+    same image_vu / box / translation as the float32 masks gathered first (the reference's Detections.filter + mask * depth,
+    ISM/model/detector.py:243), equal to the reference's capture; also the general fallback (W not a multiple of 16)."""
+    from sam6d_hip import ism
+    g = golden("ism")
+    d = ism_inputs(int(g["seed"]))
+    masks, _ = ism_masks(d["gen"], len(g["sel"]))
+    sel = torch.as_tensor(g["sel"]).long()
+    best, obj = torch.as_tensor(g["best"]).long().to(dev), torch.as_tensor(g["obj"]).long().to(dev)
+    # scatter the 150 selected proposals' masks into a (200, H, W) uint8 tensor at their original positions
+    all_u8 = torch.zeros(200, 480, 640, dtype=torch.uint8)
+    all_u8[sel] = (masks > 0).to(torch.uint8)
+    args = (d["poses"].to(dev), d["pc"].to(dev))
+    K, ds, depth = d["K"].to(dev), d["depth_scale"].to(dev), d["depth"].to(dev)
+    vu_f, xy_f, tr_f = ism.project_template_to_image(best, obj, *args, masks.to(dev), depth, K, ds)
+    vu_u, xy_u, tr_u = ism.project_template_to_image(best, obj, *args, all_u8.to(dev), depth, K, ds, mask_index=sel.to(dev))
+    vu_b, xy_b, tr_b = ism.project_template_to_image(best, obj, *args, all_u8.to(dev).bool(), depth, K, ds, mask_index=sel.to(dev))
+    for a, b in ((vu_f, vu_u), (xy_f, xy_u), (tr_f, tr_u), (vu_f, vu_b), (tr_f, tr_b)):
+        assert torch.equal(a, b)
+    assert np.array_equal(tr_u.cpu().numpy(), g["translate"]) and np.array_equal(vu_u.cpu().numpy(), g["vu"].astype(np.int32))
+    assert np.array_equal(xy_u.cpu().numpy(), g["xyxy"])
+    # general shapes (W % 16 != 0) take the scalar kernel; compare with the oracle
+    from oracle import ism_oracle as IO
+    gen = torch.Generator().manual_seed(3)
+    m2 = (torch.rand(5, 50, 70, generator=gen) > 0.6).float()
+    dp = (700 + 300 * torch.rand(50, 70, generator=gen)).to(torch.int32)
+    b2, o2 = torch.tensor([3, 1, 0, 7, 2]), torch.zeros(5, dtype=torch.long)
+    want = IO.project_template_to_image(b2, o2, d["poses"], d["pc"], m2, dp, d["K"], d["depth_scale"])
+    got, _, _ = ism.project_template_to_image(b2.to(dev), o2.to(dev), *args, m2.to(dev).bool(), dp.to(dev), K, ds)
+    assert np.array_equal(got.cpu().numpy(), want.numpy().astype(np.int32))

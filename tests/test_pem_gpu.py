@@ -382,7 +382,7 @@ def test_select_smallest_long_rows(dev, n, k):
 def test_coarse_rt_large_model_cloud(dev, P):
     """CAD clouds of 3277 .. 4096 points need more than the default 64 KB of dynamic LDS in the matrix-core scoring kernel (the
     attribute was never raised and the launch failed); 4097 takes the vector-ALU kernel.  The score of every selected hypothesis must
-    equal the vector-ALU kernel's bit for bit (same fma chain) and the pose the oracle's."""
+    equal the vector-ALU kernel's to summation order (same distance bits) and the pose the oracle's."""
     from sam6d_hip import _lib, pem
     from oracle import pem_oracle as O
     g = golden("coarse_rt")
@@ -403,7 +403,9 @@ def test_coarse_rt_large_model_cloud(dev, P):
               aux["w1"].data_ptr(), md.data_ptr(), radius.data_ptr(), 2, 196, P, 6000, 300, sc.data_ptr(), Rb.data_ptr(), tb.data_ptr(),
               best.data_ptr(), pem._s())
     torch.cuda.synchronize()
-    assert torch.equal(sc.cpu(), aux["scores"].cpu()), "matrix-core and vector-ALU hypothesis scores differ"
+    # (the distances have the same bits; the two kernels sum them over the scene points in different fixed orders)
+    rel = float(((sc - aux["scores"]).abs() / aux["scores"].abs().clamp(min=1e-20)).max())
+    assert rel < 2e-6, "matrix-core and vector-ALU hypothesis scores differ by %.2e" % rel
     assert torch.equal(best.cpu(), aux["best"].cpu())
 
 
