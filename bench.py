@@ -10,9 +10,9 @@ proposals with inputs resident in HBM when the timed region starts.
   --workload config4: ONE LM-O-style scene of 200 proposals of 8 objects, dealt round-robin to the N ranks
       (strong scaling: 200 / N proposals per rank, 25 at N = 8), unique templates + template_ids per rank.
 
-One process per GPU; the ranks all-gather the 13 floats / proposal (R, t, score) over RCCL inside the timed region.  The step is
-replayed from a hipGraph (sam6d_hip.pem.PemGraph: one graph launch instead of ~250 kernel launches per slice, micro-batch slices on
-concurrent streams of the graph); --graph 0 times the eager launch sequence instead.
+One process per GPU; the ranks all-gather the 13 floats / proposal (R, t, score) over RCCL inside the timed region.  Small batches
+(fewer than 16 proposals per GPU) replay the step from a hipGraph (sam6d_hip.pem.PemGraph: one graph launch instead of ~250 kernel
+launches); at B = 32 the eager launch sequence is the faster one and is what is timed (--graph 1 / 0 force either).
 
 Prints ONE JSON line (rank 0).  Beside the contract's keys:
   roofline          the dominant kernel (rpe_score_kernel): executed fp16-MFMA flops / dense fp16 peak, launch durations from HIP events
@@ -347,7 +347,10 @@ def main():
     ap.add_argument("--workload", choices=("config2", "config4"), default="config2")
     ap.add_argument("--cpu-proposals", type=int, default=8, help="proposals in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="config2: proposals per GPU")
-    ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a hipGraph (default); 0: eager launches")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step from a hipGraph; 0: eager launches; -1 (default): the graph "
+                    "where the eager step is bound by the host's launch rate (fewer than 16 proposals per GPU), eager otherwise -- measured "
+                    "in round 4: at B = 32 the replay is 1-2 %% SLOWER than the eager sequence (7.22 against 7.09 ms), at B = 1 it is what "
+                    "removes the launch-rate bound (`latency` in the JSON line)")
     ap.add_argument("--microbatch", type=int, default=0, help="slices of the batch on concurrent streams (0 = the default for the mode)")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="continuous steps after the timed region (0 = skip)")
     ap.add_argument("--no-ism", action="store_true", help="skip the ISM (config 3) leg reported beside the PEM metric")
@@ -418,8 +421,11 @@ def main():
     sync()
 
     opts = None if stub else pem.Options.from_env()
-    use_graph = bool(args.graph) and not stub
-    mb = args.microbatch if args.microbatch > 0 else ((2 if B >= 16 else 1) if use_graph else (opts.microbatch if opts else 1))
+    use_graph = (args.graph == 1 or (args.graph < 0 and B < 16)) and not stub
+    # micro-batch slices on concurrent streams: measured in round 4 (scratch/graph_probe2.py, scratch/concurrency_probe.py) to give
+    # nothing on this chip -- a throughput-bound kernel keeps every CU's LDS / wave slots occupied, so another stream's latency-bound
+    # launch (139 KB of LDS per workgroup) does not get on the chip beside it (L || T on two streams: 2.80 ms against 2.84 ms serial)
+    mb = args.microbatch if args.microbatch > 0 else (opts.microbatch if opts else 1)
     cfg = None if stub else dict(pem.DEFAULT_CFG, microbatch=mb)
     graph = None
     graph_error = None
@@ -698,12 +704,12 @@ def main():
         extras = world == 1 and not args.no_extras
         if extras:
             try:
-                res["latency"] = bench_latency(dev, W, bool(args.graph))
+                res["latency"] = bench_latency(dev, W, args.graph != 0)
             except Exception as e:
                 res["latency"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not cfg4:
                 try:
-                    res["config4"] = bench_config4_single(dev, W, bool(args.graph), 4)
+                    res["config4"] = bench_config4_single(dev, W, args.graph == 1, 1)
                 except Exception as e:
                     res["config4"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 try:

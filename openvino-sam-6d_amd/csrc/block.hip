@@ -1408,6 +1408,8 @@ static int tb_set_attr() {
     if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 4, 2>, TB_LDS_BYTES2(2, 2));
     if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 4, 1>, TB_LDS_BYTES2(2, 1));
     if (!rc) rc = tb_attr(token_block_kernel<0, 4, 2, TB_FD, 0, 2>, TB_LDS_BYTES2(2, 2));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 2, 2, TB_FD, 4, 2>, TB_LDS_BYTES2(2, 2));
+    if (!rc) rc = tb_attr(token_block_kernel<0, 2, 2, TB_FD, 2, 2>, TB_LDS_BYTES2(2, 2));
     if (rc) return rc;
     sam6d_setup_done_on_device(&done0);
   }
@@ -1424,7 +1426,31 @@ extern "C" int sam6d_token_block(const float* hidden, const float* x, const void
   TbArgs a{hidden, x, out, (const unsigned char*)wimage, consts, nullptr, nullptr, nullptr, M, 0, 0, 0, eps,
            sam6d_half_for(1)};
   const dim3 g64((unsigned)((M + 63) / 64));
-  if (tb_shape() == 142)
+  // Round 4: 32-token workgroups (two computing waves) while they all fit the chip at once.  A wave's chain -- 56 weight panels through
+  // the LDS ring -- is what a launch takes whatever the number of workgroups; the 6304-row launches (the cross layers: 32 clouds x 197)
+  // filled 99 of the 256 CUs with four computing waves each, which contend for the LDS reads of every panel (4 x 32 KB per panel) and
+  // leave 157 CUs idle; with two computing waves per workgroup the same rows use 197 CUs and a panel is read twice, not four times.
+  // A token's arithmetic does not depend on the workgroup shape (everything is per 16-token wave), so the results are bit-identical.
+  static int narrow = -1;
+  if (narrow < 0) {
+    const char* e = getenv("SAM6D_TB_NARROW");  // A/B: 0 = always 64-token workgroups; 2 = two loader waves instead of four
+    narrow = e ? atoi(e) : 1;
+  }
+  int dev_ = 0, cus = 256;
+  if (hipGetDevice(&dev_) == hipSuccess) {
+    static int cu_cache[SAM6D_MAX_DEVICES];
+    if (dev_ >= 0 && dev_ < SAM6D_MAX_DEVICES) {
+      if (!cu_cache[dev_] && hipDeviceGetAttribute(&cu_cache[dev_], hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess) cu_cache[dev_] = 256;
+      cus = cu_cache[dev_];
+    }
+  }
+  if (narrow && tb_shape() == 142 && (M + 31) / 32 <= cus) {
+    const dim3 g32((unsigned)((M + 31) / 32));
+    if (narrow == 2)
+      hipLaunchKernelGGL((token_block_kernel<0, 2, 2, TB_FD, 2, 2>), g32, dim3(256), TB_LDS_BYTES2(2, 2), (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL((token_block_kernel<0, 2, 2, TB_FD, 4, 2>), g32, dim3(384), TB_LDS_BYTES2(2, 2), (hipStream_t)stream, a);
+  } else if (tb_shape() == 142)
     hipLaunchKernelGGL((token_block_kernel<0, 4, 2, TB_FD, 4, 2>), g64, dim3(512), TB_LDS_BYTES2(2, 2), (hipStream_t)stream, a);
   else if (tb_shape() == 141)
     hipLaunchKernelGGL((token_block_kernel<0, 4, 2, TB_FD, 4, 1>), g64, dim3(512), TB_LDS_BYTES2(2, 1), (hipStream_t)stream, a);

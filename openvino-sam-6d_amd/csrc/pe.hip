@@ -151,8 +151,20 @@ __device__ __forceinline__ int pe_swap23(int k) { return (k & ~12) | ((k & 4) <<
 
 // BN(eval) + ReLU + fp16 hi/lo split of the 8 accumulator registers [8*half, 8*half + 8) of one transposed tile; the
 // channels of those registers are base + 8*g + 4*fk + e (g = 2*half + (j>>2), e = j&3): two 16-byte constant reads each.
+// PRE: the accumulators are first multiplied by `pre` (layer 1: the inverse of this lane's feature scale times the inverse W1 scale).
+__device__ __forceinline__ float pe_pow2_scale(float amax) {
+  // power of two s with amax * s in [2^13, 2^14); 1 for zero / non-finite input
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);
+  e = 14 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+
+template <bool PRE = false>
 __device__ __forceinline__ void pe_split8(const f32x16& acc, int half, const float* __restrict__ sc, const float* __restrict__ sh,
-                                          int fk, half8& hi, half8& lo) {
+                                          int fk, half8& hi, half8& lo, float pre = 1.0f) {
 #pragma unroll
   for (int g2 = 0; g2 < 2; ++g2) {
     const int g = 2 * half + g2;
@@ -160,7 +172,9 @@ __device__ __forceinline__ void pe_split8(const f32x16& acc, int half, const flo
     const f32x4 h4 = *reinterpret_cast<const f32x4*>(&sh[8 * g + 4 * fk]);
 #pragma unroll
     for (int e = 0; e < 4; e += 2) {
-      float v0 = fmaf(acc[4 * g + e], s4[e], h4[e]), v1 = fmaf(acc[4 * g + e + 1], s4[e + 1], h4[e + 1]);
+      float a0 = acc[4 * g + e], a1 = acc[4 * g + e + 1];
+      if constexpr (PRE) { a0 *= pre; a1 *= pre; }
+      float v0 = fmaf(a0, s4[e], h4[e]), v1 = fmaf(a1, s4[e + 1], h4[e + 1]);
       v0 = v0 > 0.f ? v0 : 0.f;
       v1 = v1 > 0.f ? v1 : 0.f;
       unsigned ph, pl;
@@ -188,7 +202,22 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
   _Float16* w3h = w2l + 64 * PH_L2;                             // [128][72], k permuted
   _Float16* w3l = w3h + 128 * PH_L3;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int e = t; e < 32 * 6; e += PH_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e];
+  // W1 as it is staged: times the power of two that puts max |W1| into [2^13, 2^14) (its fp16 lo halves then stay normal numbers); the
+  // inverse goes into the per-lane unscale of the layer-1 accumulators below.  Every workgroup computes the same scale.
+  float w1max = 0.f;
+  for (int e = t; e < 32 * 6; e += PH_WAVES * 64) w1max = fmaxf(w1max, fabsf(W1[e]));
+  w1max = wave_max_dpp(w1max);
+  if (lane == 0) w1s[7 * wave + 6] = w1max;  // (column 6 of the [32][7] image is padding)
+  __syncthreads();
+  {
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < PH_WAVES; ++w) m = fmaxf(m, w1s[7 * w + 6]);
+    w1max = m;
+  }
+  __syncthreads();
+  const float w1scale = pe_pow2_scale(w1max), w1inv = 1.0f / w1scale;
+  for (int e = t; e < 32 * 6; e += PH_WAVES * 64) w1s[(e / 6) * 7 + (e % 6)] = W1[e] * w1scale;
   for (int e = t; e < 64 * 32; e += PH_WAVES * 64) {
     const float v = W2[e];
     const _Float16 h = (_Float16)v;
@@ -196,8 +225,12 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     w2h[o] = h;
     w2l[o] = (_Float16)(v - (float)h);
   }
+  // Layer 3 ends in max over the ball of BN(acc) = fma(acc, sc3, sh3).  With the SIGN of sc3[ch] folded into row ch of W3 (exact) the
+  // map acc -> fma(acc, |sc3|, sh3) is monotone non-decreasing, so the max commutes with it bit for bit: the per-tile epilogue is a
+  // running max over the raw accumulators (v_max3: 8 instructions per 16 values instead of 16 fma + 16 max) and the fma runs once per
+  // point (stamps of round 3: the max epilogue cost 1.4-1.7 k cycles per tile beside 2 k cycles of MFMA issue).
   for (int e = t; e < 128 * 64; e += PH_WAVES * 64) {
-    const float v = W3[e];
+    const float v = sc3[e >> 6] < 0.f ? -W3[e] : W3[e];
     const _Float16 h = (_Float16)v;
     const int o = (e >> 6) * PH_L3 + pe_swap23(e & 63);
     w3h[o] = h;
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
   }
   if (t < 32) { bn[t] = sc1[t]; bn[32 + t] = sh1[t]; }
   if (t < 64) { bn[64 + t] = sc2[t]; bn[128 + t] = sh2[t]; }
-  if (t < 128) { bn[192 + t] = sc3[t]; bn[320 + t] = sh3[t]; }
+  if (t < 128) { bn[192 + t] = fabsf(sc3[t]); bn[320 + t] = sh3[t]; }
   __syncthreads();
   const int fr = lane & 31, fk = lane >> 5;
   const int ntile = S >> 5;
@@ -248,7 +281,7 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     w1a = __builtin_bit_cast(half8, fk ? pe_u4{l01, l23, l45, 0u} : pe_u4{h01, h23, h45, 0u});
     w1b = __builtin_bit_cast(half8, fk ? pe_u4{0u, 0u, 0u, 0u} : pe_u4{h01, h23, h45, 0u});
   }
-  float mx[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0, so 0 is a neutral start for the max
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // running max of the raw layer-3 accumulators of the point
   int wrow = fr, wk = 8 * fk;  // this lane's row / k offset in the weight images
   while (pA < total) {
     // the weight reads are loop-invariant: keep them inside the loop (hoisted, they would not fit the register file)
@@ -272,11 +305,22 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     f32x16 a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+    // Range safety of the split (round 4): the six features of this lane's neighbour are scaled by the power of two that puts their
+    // largest magnitude into [2^13, 2^14) -- raw coordinates below 0.125 had fp16-subnormal lo halves (an ABSOLUTE error floor of 3e-8
+    // instead of a relative one) and coordinates >= 65504 overflowed to inf, where the reference is fine.  The scale is per lane
+    // (= per neighbour = per column of the transposed product), so it is undone exactly on the lane's own accumulators.
+    float finv;
     {
+      const float f0 = xA - qxA, f1 = yA - qyA, f2 = zA - qzA;
+      const float fm = fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(xA))), fmaxf(fabsf(yA), fabsf(zA)));
+      const int ex = (int)(__float_as_uint(fm) >> 23);  // biased exponent: fm in [2^(ex-127), 2^(ex-126))
+      const int se = min(267 - ex, 240);                // biased exponent of the scale 2^(140 - ex), capped for fm ~ 0
+      const float fs = __uint_as_float((unsigned)se << 23);
+      finv = __uint_as_float((unsigned)(254 - se) << 23) * w1inv;
       unsigned h01, l01, h23, l23, h45, l45;
-      sam6d_split2_f16(xA - qxA, yA - qyA, h01, l01);
-      sam6d_split2_f16(zA - qzA, xA, h23, l23);
-      sam6d_split2_f16(yA, zA, h45, l45);
+      sam6d_split2_f16(f0 * fs, f1 * fs, h01, l01);
+      sam6d_split2_f16(f2 * fs, xA * fs, h23, l23);
+      sam6d_split2_f16(yA * fs, zA * fs, h45, l45);
       const half8 bx = __builtin_bit_cast(half8, pe_u4{h01, h23, h45, 0u});
       const half8 bl = __builtin_bit_cast(half8, fk ? pe_u4{0u, 0u, 0u, 0u} : pe_u4{l01, l23, l45, 0u});
       a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1a, bx, a1, 0, 0, 0);
@@ -284,7 +328,7 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     }
     half8 h1h[2], h1l[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) pe_split8(a1, s, bn, bn + 32, wk >> 3, h1h[s], h1l[s]);
+    for (int s = 0; s < 2; ++s) pe_split8<true>(a1, s, bn, bn + 32, wk >> 3, h1h[s], h1l[s], finv);
     // ---- layer 2 (transposed): D2T[ch2][nb] = W2[ch2][k] H1T[k][nb]
     f32x16 a2[2];
 #pragma unroll
@@ -325,15 +369,16 @@ __global__ __launch_bounds__(PH_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3
     for (int c = 0; c < 4; ++c) {
       float m = mx[c];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaf(a3[c][r], s3[c], h3[c]));
+      for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, a3[c][r]), a3[c][r + 1]);
       mx[c] = m;
     }
     if (tA == ntile - 1) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float m = fmaxf(mx[c], xor32_f32(mx[c]));
+        float m = fmaxf(mx[c], xor32_f32(mx[c]));
+        m = fmaxf(fmaf(m, s3[c], h3[c]), 0.f);  // BN (|scale|: the sign is in W3) + ReLU of the maximum = the maximum of BN + ReLU
         if (fk == 0) out[(long)pA * ldo + off + c * 32 + fr] = m;
-        mx[c] = 0.f;
+        mx[c] = -INFINITY;
       }
     }
     // ---- rotate the pipeline

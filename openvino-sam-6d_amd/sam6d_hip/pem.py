@@ -532,12 +532,33 @@ PROFILE = None
 PROFILE_NAMES = None
 
 
+# Micro-batch pipeline (pem_match with microbatch > 1): the slices run the same launch chain on their own streams.  Started together they
+# stay in lock-step -- both in a throughput-bound kernel (which then share the chip: no gain) or both in a latency-bound one (whose time
+# does not depend on the batch size: no gain either).  What pays is a slice's latency-bound chain (197-token layers, pose solver) BESIDE
+# another slice's throughput-bound kernel, so the big kernels take turns: occurrence k of a big kernel in slice s waits for occurrence k
+# of the same kernel in slice s - 1 (an event recorded earlier in program order: slices are issued one after the other).  Slice 0 runs
+# free, slice 1 trails it by one big kernel, and so on: at any time at most one slice is inside a given big kernel while the others are
+# in their latency-bound stretches.  _PIPE = (events, slice index, per-slice occurrence counters) while a slice is being issued.
+_PIPE = None
+_BIG = frozenset(("rpe_score_kernel", "linattn_layer", "score_hyp", "fine_match", "linear_norm_split", "pe_mlp", "gemm_big"))
+
+
 class _Timed:
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
         self.on = PROFILE is not None and (PROFILE_NAMES is None or self.name in PROFILE_NAMES)
+        self.turn = None
+        if _PIPE is not None and self.name in _BIG:
+            ev, s, counts = _PIPE
+            k = counts.get(self.name, 0)
+            counts[self.name] = k + 1
+            self.turn = (s, self.name, k)
+            if s > 0:
+                e = ev.get((s - 1, self.name, k))
+                if e is not None:
+                    torch.cuda.current_stream().wait_event(e)
         if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
@@ -547,6 +568,10 @@ class _Timed:
         if self.on:
             self.b.record()
             PROFILE.setdefault(self.name, []).append((self.a, self.b))
+        if self.turn is not None and _PIPE is not None:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream())
+            _PIPE[0][self.turn] = e
 
 
 @on_tensor_device
@@ -1030,9 +1055,10 @@ def pe_apply(pts, idx12, W, dst, dst_off, dst_sb, max_wg=0):
     for k in range(2):
         idx = idx12[k]
         L = W.pe["mlp"][k]
-        _lib.call("sam6d_pe_mlp_max_wg", _p(pts), _p(idx), Bp, N, idx.shape[2], _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
-                  _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),
-                  _p(feat), 2 * 128, k * 128, int(max_wg), _s())
+        with _Timed("pe_mlp"):
+            _lib.call("sam6d_pe_mlp_max_wg", _p(pts), _p(idx), Bp, N, idx.shape[2], _p(L[0]["w"]), _p(L[0]["scale"]), _p(L[0]["shift"]),
+                      _p(L[1]["w"]), _p(L[1]["scale"]), _p(L[1]["shift"]), _p(L[2]["w"]), _p(L[2]["scale"]), _p(L[2]["shift"]),
+                      _p(feat), 2 * 128, k * 128, int(max_wg), _s())
     m3 = W.pe["mlp3"]
     gemm(feat, m3.w, m3.b, dst, N, C, C, C, C, C, c_off=dst_off, residual=dst, r_off=dst_off, ldr=C, batch=Bp, sA=N * C,
          sC=dst_sb, sR=dst_sb, w16=m3.w16())
@@ -1558,7 +1584,9 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     fine_static_b(dpu, D, grp, W, shared_template, max_wg=opts.pe_side_wgs)
-        elif overlap:
+        elif overlap and (mb <= 1 or cfg.get("mb_overlap", False)):
+            # (inside a micro-batch slice the pipeline of slices provides the overlap; a second level of forked streams is also what
+            #  hipStreamEndCapture crashed on when the slices were captured into a graph: scratch/graph_probe2.py)
             D, side = fork_fine_static(dpu, df, side_key)
         elif tmpl is not None:
             D = fine_static(dpu, df, W, cfg, shared_template)
@@ -1589,16 +1617,29 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
         _ensure_w16(W)
     per = (B + mb - 1) // mb
     spans = [(i * per, min(B, (i + 1) * per)) for i in range(mb)]
-    preps = [prepare(lo, hi) for lo, hi in spans]  # serial, on the caller's stream
+    # (until round 4 the slices' FPS / gathers / geometric indices ran serially on the caller's stream first -- defence in depth for the
+    #  packed-fp32 hazard, which the build flags have removed since; FPS is latency-bound, 0.17 ms whatever the batch, so k serial
+    #  prologues cost k times that: each slice now runs its own prologue on its own stream)
+    serial_prep = bool(cfg.get("mb_serial_prepare", False))
+    preps = [prepare(lo, hi) for lo, hi in spans] if serial_prep else [None] * len(spans)
     outs = []
+    global _PIPE
+    events = {}
     for i, (lo, hi) in enumerate(spans):
         st = _side_stream(dense_pm.device, ("mb", i))
         st.wait_stream(main)
-        with torch.cuda.stream(st):
-            outs.append(rest(preps[i], lo, hi, ("mb", i, "side")))
-        for tns in preps[i][:5]:
-            for x in (tns if isinstance(tns, tuple) else (tns,)):
-                x.record_stream(st)
+        _PIPE = (events, i, {}) if cfg.get("mb_pipeline", True) else None
+        try:
+            with torch.cuda.stream(st):
+                if preps[i] is None:
+                    preps[i] = prepare(lo, hi)
+                outs.append(rest(preps[i], lo, hi, ("mb", i, "side")))
+        finally:
+            _PIPE = None
+        if serial_prep:
+            for tns in preps[i][:5]:
+                for x in (tns if isinstance(tns, tuple) else (tns,)):
+                    x.record_stream(st)
     R = _empty((B, 3, 3), dense_pm)
     t = _empty((B, 3), dense_pm)
     sc = _empty((B,), dense_pm)

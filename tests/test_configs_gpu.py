@@ -446,3 +446,60 @@ def test_config4_200_proposals_8_objects_template_ids(dev, W):
             for x, y in zip(part, rep):
                 assert torch.equal(x, y)
     assert torch.equal(R, whole[0]) and torch.equal(t, whole[1]) and torch.equal(s, whole[2])
+
+
+# ------------------------------------------------------------------------------------------- weight-guarded fallback routes, end to end
+@pytest.mark.parametrize("case", ["fused_guard_no", "image_guard_no", "three_product_stage1"])
+def test_weight_guard_fallback_routes_end_to_end_vs_oracle(dev, sd, case):
+    """The default fast paths are chosen per WEIGHT SET on the host (fused-RPE range guard, fp16-image guard, two-product stage 1): the
+    released checkpoint -- not available offline -- may send any of them to its "no" branch.  Each branch is forced here and checked END
+    TO END against the oracle with the staged contract of test_config2_full_batch_vs_oracle (test_rpe_fused_range_guard checks the
+    embedding alone): (1) FPS indices bit-exact and the COARSE ATTENTION -- the output of three geometric-transformer blocks through the
+    routed kernels -- within 1e-4; (2) the fine stage started from the ORACLE's coarse pose (pem_match(init_pose=...)) gives the
+    oracle's final R, t, score within 1e-4 (the coarse pose itself is a discrete choice on random features, proved link by link there).
+    fused / image guard: proj_d and proj_a (weights and biases) are scaled by s and every proj_p weight by 1 / s -- the same function in
+    exact arithmetic, but the projected embedding leaves the fp16 range of the fused score kernel (s = 20: materialised embedding +
+    attention_kernel<RPE>) or of the split-precision embedding images altogether (s = 4000: the exact fp32 embedding kernel).
+    three_product_stage1: sigma_a = 7.5 doubles the angular index range, for which the host check refuses the two-product form."""
+    from oracle import pem_oracle as O
+    from sam6d_hip import pem, synth
+    sd2 = dict(sd)
+    cfg, ocfg = dict(pem.DEFAULT_CFG), dict(O.DEFAULT_CFG)
+    if case == "three_product_stage1":
+        cfg["sigma_a"] = ocfg["sigma_a"] = 7.5
+    else:
+        s_ = 20.0 if case == "fused_guard_no" else 4000.0
+        for k in sd:
+            if k.startswith("geo_embedding.proj_"):
+                sd2[k] = sd[k] * s_
+            elif k.endswith("attention.proj_p.weight"):
+                sd2[k] = sd[k] / s_
+    W2 = pem.PemWeights(sd2, dev)
+    paths = pem.describe_paths(W2, cfg)
+    if case == "three_product_stage1":
+        assert paths["rpe_stage1_products"] == 3, paths
+    elif case == "fused_guard_no":
+        assert paths["rpe_stage1_products"] is None and paths["fused_rpe_guard_passed"] is False and "geo_cheb" in paths["embedding_rows"], paths
+    else:
+        assert paths["fused_rpe_guard_passed"] is False and "exact fp32" in paths["embedding_rows"], paths
+    B = 2
+    inp = synth.config2_inputs(B=B, seed=23)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    oR0, ot0, oR, ot, os_ = [], [], [], [], []
+    R, t, s, aux = pem.pem_match(*[d[k] for k in keys], W2, d["rand"], cfg=cfg, return_aux=True)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all() and torch.isfinite(s).all()
+    worst = 0.0
+    with torch.no_grad():
+        for b in range(B):
+            o = _oracle_proposal(O, inp, b, sd2, ocfg)
+            assert torch.equal(aux["fps_idx_m"][b:b + 1].cpu(), o["im"]) and torch.equal(aux["fps_idx_o"][b:b + 1].cpu(), o["io"])
+            da = _d(aux["coarse"]["atten"][b:b + 1], o["coarse"]["atten"])
+            worst = max(worst, da)
+            assert da <= 1e-4, "%s, proposal %d: coarse attention off by %.2e" % (case, b, da)
+            oR0.append(o["R0"]); ot0.append(o["t0"]); oR.append(o["R"]); ot.append(o["t"]); os_.append(o["s"])
+    R2, t2, s2 = pem.pem_match(*[d[k] for k in keys], W2, d["rand"], cfg=cfg,
+                               init_pose=(torch.cat(oR0).to(dev), torch.cat(ot0).to(dev)))
+    print("\n%s: coarse attention %.2e; fine stage from the oracle's coarse pose: dR %.2e dt %.2e ds %.2e"
+          % (case, worst, _d(R2, torch.cat(oR)), _d(t2, torch.cat(ot)), _d(s2, torch.cat(os_))))
+    _close(R2, torch.cat(oR), 1e-4, case + ": R"); _close(t2, torch.cat(ot), 1e-4, case + ": t"); _close(s2, torch.cat(os_), 1e-4, case + ": score")

@@ -236,6 +236,43 @@ def test_pe_mlp_max_register_chained_vs_exact_and_fp64(dev, W, B, N, S):
     assert d < 3e-6 * max(1.0, float(exact.abs().max()))
 
 
+@pytest.mark.parametrize("extent,offset", [(1e-2, 0.0), (3e-4, 0.0), (1.0, 8.0), (1500.0, 0.0), (3.0e5, 2.0e5)])
+def test_pe_mlp_max_coordinate_range(dev, W, extent, offset):
+    """layer 1 of the PE MLP splits the raw coordinates into fp16 hi / lo halves.  Unscaled, a cloud of extent ~1e-2 had
+    subnormal lo halves (an absolute error floor), and millimetre-unit clouds beyond 65504 overflowed to inf.  With the per-neighbour
+    power-of-two scale the error is RELATIVE to the features' magnitude for any extent: checked against a float64 recompute, with the
+    bound RELATIVE to the output scale (BN shifts zeroed so that the outputs follow the coordinates' magnitude)."""
+    from sam6d_hip import _lib
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("default (fp16x3) mode only")
+    B, N, S = 2, 600, 32
+    gen = torch.Generator().manual_seed(int(extent * 1000) % 1000 + 17)
+    pts = (torch.rand(B, N, 3, generator=gen) - 0.5) * extent + offset
+    idx = torch.randint(0, N, (B, N, S), generator=gen, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(N, dtype=torch.int32)[None]
+    # BN shifts zeroed: the MLP is then positively homogeneous, the outputs scale with the coordinates and the bound below is relative
+    L = [dict(w=l["w"], scale=l["scale"], shift=torch.zeros_like(l["shift"])) for l in W.pe["mlp"][0]]
+    pts_d, idx_d = pts.to(dev), idx.to(dev)
+    out = torch.zeros((B * N, 128), device=dev)
+    _lib.call("sam6d_pe_mlp_max", pts_d.data_ptr(), idx_d.data_ptr(), B, N, S, L[0]["w"].data_ptr(), L[0]["scale"].data_ptr(),
+              L[0]["shift"].data_ptr(), L[1]["w"].data_ptr(), L[1]["scale"].data_ptr(), L[1]["shift"].data_ptr(), L[2]["w"].data_ptr(),
+              L[2]["scale"].data_ptr(), L[2]["shift"].data_ptr(), out.data_ptr(), 128, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    nb = torch.gather(pts.double()[:, None].expand(B, N, N, 3), 2, idx.long()[..., None].expand(B, N, S, 3))
+    # the kernel (like the reference: fine_point_matching.py:117) forms new_xyz = pts + 1e-8 in fp32 first
+    q = (pts + 0.00000001).double()
+    h = torch.cat([nb - q[:, :, None], nb], -1)
+    for l in L:
+        h = (h @ l["w"].double().cpu().t() * l["scale"].double().cpu() + l["shift"].double().cpu()).clamp(min=0)
+    want = h.max(2).values.reshape(B * N, 128)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all(), "non-finite PE features at extent %g" % extent
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    print("\npe_mlp_max extent %g offset %g: max abs err %.2e of scale %.3g" % (extent, offset, err, scale))
+    assert err <= 3e-6 * scale, "extent %g: %.3e of %.3e" % (extent, err, scale)
+
+
 def test_feature_similarity_golden(dev):
     from sam6d_hip import pem
     g = golden("similarity")
