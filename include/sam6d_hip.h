@@ -409,6 +409,12 @@ int sam6d_ism_cosine(const float* query, const float* ref, int Nq, int No, int N
  * indices of the queries with score > thresh, *nsel their count (device int). */
 int sam6d_ism_semantic(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem, int* obj, int* best,
                        int* sel, int* nsel, void* stream);
+/* sam6d_ism_semantic with the survivors written out compacted as the tensors the reference's caller holds after its boolean-mask
+ * indexing (ISM/model/detector.py:284-296, best_template_pose :198-207): sel / obj_sel / best_sel (Nq) i64, sem_sel (Nq) f32, the first
+ * nsel[0] entries valid; sem_ws / obj_ws / best_ws (Nq) are per-query scratch. */
+int sam6d_ism_semantic_compact(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem_ws, int* obj_ws,
+                               int* best_ws, long long* sel, long long* obj_sel, float* sem_sel, long long* best_sel, int* nsel,
+                               void* stream);
 /* replaces compute_straight + compute_visible_ratio reductions (ISM/model/loss.py:52-76) over sim (Ns,P,P). */
 int sam6d_ism_patch_scores(const float* sim, const float* q_appe, int Ns, int P, int D, float thred, float* appe, float* vis,
                            void* stream);
@@ -452,6 +458,11 @@ int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, float* iou, i
 /* final score (ISM/model/detector.py:384): (sem[sel] + appe + geo*vis) / (2 + vis); geo NULL = the scalar-0.0 IoU case. */
 int sam6d_ism_final_score(const float* sem, const float* appe, const float* geo, const float* vis, const int* sel, int Ns,
                           float* out, void* stream);
+/* sam6d_ism_final_score (ISM/model/detector.py:384) with the IoU quirk of ISM/utils/bbox_utils.py:214-220 decided on the DEVICE: geo is
+ * used only while all_positive[0] (the flag sam6d_ism_iou leaves) is non-zero, else the geometric term is 0 for every proposal -- no host
+ * read-back between the IoU and the final score. */
+int sam6d_ism_final_score_flag(const float* sem, const float* appe, const float* geo, const float* vis, const int* all_positive, int Ns,
+                               float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Rows SURVEY 8f marks "next" (callers either side of the path).

@@ -843,6 +843,23 @@ __global__ __launch_bounds__((WAVES + LOADERS) * 64, 2) void token_block_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Measured and removed, round 4: the layer tail with the FFN split over TWO waves per 16-token group.  The primary
+// wave of a group ran linear + residual + LayerNorm and handed the normalised row (fp16 hi / lo fragments, 16 KB per group) to a
+// secondary wave through LDS; primary and secondary then ran the hidden chunks {0, 1} and {2, 3} at once (a 64 KB ring slot held one
+// panel pair of either role, 20 steps instead of 56 panels per chain), and the secondary's partial squeeze accumulators came back
+// through LDS for the second residual + LayerNorm: two LDS exchanges per layer (round 3's rejected form split every product and needed
+// seven), primary and secondary of a group on one SIMD so that one's row epilogues sit under the other's MFMAs.  232 VGPRs, no spills,
+// all 63 tests of tests/test_block_gpu.py green (the hidden chunks summed as (0 + 1) + (2 + 3)).  Times (scratch/run_block.py, one box,
+// us per launch): 12608 rows 43.7 against 40.7 for token_block_kernel, 6304 rows 39.7 against 34.0 (the 32-token shape below).
+// Why it does not pay: the chain is bound by the LDS, not by the serial epilogues.  Every 16-token wave reads each weight panel from
+// LDS whole -- 2 KB of fragments per three MFMAs, i.e. 43 B / clk per wave at the full MFMA rate, 171 B / clk for four waves beside the
+// ring's DMA writes, against the ~130-150 B / clk a CU delivers in practice -- so a K = 256 panel takes ~1420 cycles for 768 cycles of
+// MFMA issue, and eight computing waves per workgroup double the reads per step while the two roles' panel pairs double the DMA bytes
+// in flight: a step of the split kernel took ~3 000 cycles.  Fewer LDS bytes per MFMA would need 32-token waves on v_mfma_f32_32x32x16
+// (twice the flops per fragment byte), whose operands + accumulators (128 + 128 registers before the FFN hidden chunks) only fit one
+// wave per SIMD and leave half of the SIMDs without a wave at 49 tokens per CU -- priced at 36 us per launch, not built.
+// What did help: two computing waves per workgroup where the rows still fill the chip (sam6d_token_block below).
+// ---------------------------------------------------------------------------------------------------------------------
 // Front of the RPE self-attention layer (RPEMultiHeadAttention.forward, PEM/model/transformer.py:395-405, with proj_p folded into the
 // query as attention.hip / rpe.hip describe): one launch instead of three GEMMs
 //     qkv = x Wqkv^T + b          (M, 768)   written (q | k | v)

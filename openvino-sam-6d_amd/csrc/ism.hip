@@ -141,6 +141,49 @@ __global__ __launch_bounds__(1024) void ism_select_kernel(const float* __restric
   }
 }
 
+// ism_select_kernel with the survivors' values written out compacted, as the int64 / float tensors the caller indexes with
+// (detector.py:284-296: idx_selected_proposals, pred_idx_objects, semantic_score, best_template): no follow-up gathers / casts.
+__global__ __launch_bounds__(1024) void ism_select_compact_kernel(const float* __restrict__ sem, const int* __restrict__ obj,
+                                                                  const int* __restrict__ best, int Nq, float thresh,
+                                                                  long long* __restrict__ sel, long long* __restrict__ obj_sel,
+                                                                  float* __restrict__ sem_sel, long long* __restrict__ best_sel,
+                                                                  int* __restrict__ nsel) {
+  __shared__ int wcnt[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float v = t < Nq ? sem[t] : 0.f;
+  const bool keep = (t < Nq) && (v > thresh);
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wcnt[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wcnt[w];
+  if (keep) {
+    const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+    sel[k] = t;
+    obj_sel[k] = obj[t];
+    sem_sel[k] = v;
+    best_sel[k] = best[t];
+  }
+  if (t == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; ++w) tot += wcnt[w];
+    *nsel = tot;
+  }
+}
+
+extern "C" int sam6d_ism_semantic_compact(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem_ws, int* obj_ws,
+                                          int* best_ws, long long* sel, long long* obj_sel, float* sem_sel, long long* best_sel, int* nsel,
+                                          void* stream) {
+  SAM6D_REQUIRE(scores && sem_ws && obj_ws && best_ws && sel && obj_sel && sem_sel && best_sel && nsel, "ism_semantic_compact: null pointer");
+  SAM6D_REQUIRE(Nq >= 0 && Nq <= 1024 && No > 0 && Nt > 0 && Nt <= 256 && mode >= 0 && mode <= 2,
+                "ism_semantic_compact: need Nq <= 1024, Nt <= 256, mode in {0 avg_5, 1 mean, 2 max}");
+  hipStream_t s = (hipStream_t)stream;
+  if (Nq > 0) hipLaunchKernelGGL(ism_semantic_kernel, dim3(Nq), dim3(64), 0, s, scores, No, Nt, mode, sem_ws, obj_ws, best_ws);
+  hipLaunchKernelGGL(ism_select_compact_kernel, dim3(1), dim3(1024), 0, s, sem_ws, obj_ws, best_ws, Nq, thresh, sel, obj_sel, sem_sel,
+                     best_sel, nsel);
+  SAM6D_LAUNCH_CHECK("ism_semantic_compact");
+}
+
 extern "C" int sam6d_ism_semantic(const float* scores, int Nq, int No, int Nt, int mode, float thresh, float* sem, int* obj,
                                   int* best, int* sel, int* nsel, void* stream) {
   SAM6D_REQUIRE(scores && sem && obj && best && sel && nsel, "ism_semantic: null pointer");
@@ -718,10 +761,12 @@ extern "C" int sam6d_ism_iou(const int* xyxy, const long long* boxes, int Ns, fl
 }
 
 __global__ void ism_final_kernel(const float* __restrict__ sem, const float* __restrict__ appe, const float* __restrict__ geo,
-                                 const float* __restrict__ vis, const int* __restrict__ sel, int Ns, float* __restrict__ out) {
+                                 const float* __restrict__ vis, const int* __restrict__ sel, int Ns, float* __restrict__ out,
+                                 const int* __restrict__ all_positive) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= Ns) return;
-  const float g = geo ? geo[i] : 0.f;  // geo == NULL: the scalar-0.0 IoU quirk
+  // geo == NULL, or the device flag of sam6d_ism_iou cleared: the scalar-0.0 IoU quirk
+  const float g = (geo && (!all_positive || *all_positive)) ? geo[i] : 0.f;
   const float s = sem[sel ? sel[i] : i];
   out[i] = ((s + appe[i]) + g * vis[i]) / ((1.f + 1.f) + vis[i]);
 }
@@ -730,6 +775,15 @@ extern "C" int sam6d_ism_final_score(const float* sem, const float* appe, const 
                                      int Ns, float* out, void* stream) {
   SAM6D_REQUIRE(sem && appe && vis && out && Ns >= 0, "ism_final_score: bad arguments");
   if (Ns == 0) return 0;
-  hipLaunchKernelGGL(ism_final_kernel, dim3(cdiv(Ns, 256)), dim3(256), 0, (hipStream_t)stream, sem, appe, geo, vis, sel, Ns, out);
+  hipLaunchKernelGGL(ism_final_kernel, dim3(cdiv(Ns, 256)), dim3(256), 0, (hipStream_t)stream, sem, appe, geo, vis, sel, Ns, out, nullptr);
   SAM6D_LAUNCH_CHECK("ism_final_score");
+}
+
+extern "C" int sam6d_ism_final_score_flag(const float* sem, const float* appe, const float* geo, const float* vis, const int* all_positive,
+                                          int Ns, float* out, void* stream) {
+  SAM6D_REQUIRE(sem && appe && geo && vis && all_positive && out && Ns >= 0, "ism_final_score_flag: bad arguments");
+  if (Ns == 0) return 0;
+  hipLaunchKernelGGL(ism_final_kernel, dim3(cdiv(Ns, 256)), dim3(256), 0, (hipStream_t)stream, sem, appe, geo, vis, nullptr, Ns, out,
+                     all_positive);
+  SAM6D_LAUNCH_CHECK("ism_final_score_flag");
 }

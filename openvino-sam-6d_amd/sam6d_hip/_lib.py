@@ -84,6 +84,8 @@ SIGNATURES = {
     "sam6d_ism_project2": [c_p, c_i, c_p, c_p, c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "sam6d_ism_translate_maps": [c_p, c_p, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p],
     "sam6d_ism_iou": [c_p, c_p, c_i, c_p, c_p, c_p],
+    "sam6d_ism_semantic_compact": [c_p, c_i, c_i, c_i, c_i, c_f] + [c_p] * 9,
+    "sam6d_ism_final_score_flag": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "sam6d_ism_final_score": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "sam6d_radius_normalize": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "sam6d_masked_patch_normalize": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p],

@@ -27,16 +27,14 @@ def semantic_select(scores, aggregation="avg_5", confidence_thresh=0.2):
     if aggregation not in _MODES:
         raise NotImplementedError("aggregation_function %r (implemented: avg_5, mean, max)" % aggregation)
     Nq, No, Nt = scores.shape
-    sem = _empty((Nq,), scores)
-    obj = _empty((Nq,), scores, torch.int32)
-    best = _empty((Nq,), scores, torch.int32)
-    sel = _empty((max(Nq, 1),), scores, torch.int32)
-    nsel = _empty((1,), scores, torch.int32)
-    _lib.call("sam6d_ism_semantic", _p(scores), Nq, No, Nt, _MODES[aggregation], float(confidence_thresh), _p(sem), _p(obj),
-              _p(best), _p(sel), _p(nsel), _s())
-    k = int(nsel.item())
-    sel = sel[:k].long()
-    return sel, obj.long()[sel], sem[sel], best.long()[sel]
+    n = max(Nq, 1)
+    ws_i = _empty((2 * n + 1,), scores, torch.int32)   # obj | best | count
+    ws_f = _empty((2 * n,), scores)                    # sem (per query) | sem (compacted)
+    out64 = _empty((3 * n,), scores, torch.int64)      # sel | obj | best, compacted
+    _lib.call("sam6d_ism_semantic_compact", _p(scores), Nq, No, Nt, _MODES[aggregation], float(confidence_thresh), _p(ws_f), _p(ws_i),
+              _p(ws_i, n), out64.data_ptr(), out64.data_ptr() + 8 * n, _p(ws_f, n), out64.data_ptr() + 16 * n, _p(ws_i, 2 * n), _s())
+    k = int(ws_i[2 * n].item())  # the one host read-back of the pass (the survivors' count fixes every later shape)
+    return out64[:k], out64[n:n + k], ws_f[n:n + k], out64[2 * n:2 * n + k]
 
 
 @on_tensor_device
@@ -162,23 +160,31 @@ def translate_masked_depth_maps(masked_depth, K, depth_scale):
 
 
 @on_tensor_device
-def compute_iou(xyxy, boxes):
-    """ISM/utils/bbox_utils.py:197-222 incl. the quirk: any non-positive overlap => the python float 0.0."""
+def compute_iou(xyxy, boxes, return_flag=False):
+    """ISM/utils/bbox_utils.py:197-222 incl. the quirk: any non-positive overlap => the python float 0.0.
+    return_flag=True: (iou (Ns,), all_positive (1,) i32 device flag) without the host read-back -- final_score(..., all_positive=flag)
+    applies the quirk on the device."""
     Ns = xyxy.shape[0]
     iou = torch.empty(Ns, dtype=torch.float32, device=xyxy.device)
     flag = torch.empty(1, dtype=torch.int32, device=xyxy.device)
     a = xyxy.to(torch.int32).contiguous()
     b = boxes.to(torch.int64).contiguous()
     _lib.call("sam6d_ism_iou", a.data_ptr(), b.data_ptr(), Ns, _p(iou), flag.data_ptr(), _s())
+    if return_flag:
+        return iou, flag
     return iou if int(flag.item()) == 1 else 0.0
 
 
 @on_tensor_device
-def final_score(sem, appe, geo, vis):
-    """ISM/model/detector.py:384."""
+def final_score(sem, appe, geo, vis, all_positive=None):
+    """ISM/model/detector.py:384.  geo: the IoU tensor, or the float 0.0 of the quirk; with all_positive (the device flag of
+    compute_iou(return_flag=True)) the quirk is decided on the device."""
     Ns = appe.shape[0]
     out = _empty((Ns,), appe)
     g = geo if torch.is_tensor(geo) else None
+    if all_positive is not None and g is not None:
+        _lib.call("sam6d_ism_final_score_flag", _p(sem.contiguous()), _p(appe), _p(g), _p(vis), all_positive.data_ptr(), Ns, _p(out), _s())
+        return out
     _lib.call("sam6d_ism_final_score", _p(sem.contiguous()), _p(appe), _p(g), _p(vis), None, Ns, _p(out), _s())
     return out
 

@@ -46,7 +46,6 @@ class Options:
         self_attn=True,     # q.k^T + softmax + P.v of the RPE self layers in one launch per (cloud, head)
         fused_out=True,     # fine out_proj + normalize + operand split in one pass
         rows_linear=True,   # sparse-token projections on the panel kernel
-        cross_fused=True,   # a cross layer's attention + layer tail in one launch (csrc/xblock.hip)
         rpe_products=0,     # 0: what the weight set allows (geo_cheb_a_packed); 3: always three stage-1 products
         fused_rpe=True,     # RPE attention without the embedding tensor
         fused_fine=True,    # fine similarity + soft assignment as one pipeline (finematch.hip)
@@ -56,7 +55,7 @@ class Options:
     )
     ENV = dict(matmul_mode="SAM6D_MATMUL_MODE", w16="SAM6D_W16", fused_block="SAM6D_FUSED_BLOCK", fused_ln="SAM6D_FUSED_LN",
                fused_front="SAM6D_FUSED_FRONT", score_mfma="SAM6D_SCORE_MFMA", bq_grid="SAM6D_BQ_GRID", xattn_kv="SAM6D_XATTN_KV",
-               self_attn="SAM6D_SELF_ATTN", fused_out="SAM6D_FUSED_OUT", rows_linear="SAM6D_ROWS_LINEAR", cross_fused="SAM6D_CROSS_FUSED",
+               self_attn="SAM6D_SELF_ATTN", fused_out="SAM6D_FUSED_OUT", rows_linear="SAM6D_ROWS_LINEAR",
                rpe_products="SAM6D_RPE_PRODUCTS", fused_rpe="SAM6D_FUSED_RPE", fused_fine="SAM6D_FUSED_FINE", overlap="SAM6D_OVERLAP",
                microbatch="SAM6D_MICROBATCH", pe_side_wgs="SAM6D_PE_SIDE_WGS")
     __slots__ = tuple(DEFAULTS) + ("mode",)
@@ -82,7 +81,6 @@ class Options:
         self.fused_front = bool(self.fused_front) and self.fused_block
         self.fused_out = bool(self.fused_out) and self.fused_block
         self.rows_linear = bool(self.rows_linear) and self.fused_block
-        self.cross_fused = bool(self.cross_fused) and self.fused_block
         self.fused_rpe = bool(self.fused_rpe) and split
         self.rpe_products = int(self.rpe_products)
         self.microbatch = int(self.microbatch)
@@ -1677,8 +1675,7 @@ def describe_paths(W, cfg=DEFAULT_CFG, options=None):
         "gemm_route": ("gemm_nt_h3_kernel, pre-split fp16 weight halves" if o.w16 else "gemm_nt_h3_kernel, weights split per tile") if split
                       else "gemm_nt_kernel (v_mfma_f32_32x32x2_f32)",
         "layer_tails": "token_block_kernel (one launch per tail)" if o.fused_block else "GEMM + LayerNorm launches",
-        "cross_layers": ("xblock: attention + tail in one launch" if (o.cross_fused and o.xattn_kv) else
-                         "xattn_kernel<kv inside> + token_block_kernel" if o.xattn_kv else "kv GEMM + xattn_kernel + token_block_kernel") if o.fused_block
+        "cross_layers": ("xattn_kernel<kv inside> + token_block kernel" if o.xattn_kv else "kv GEMM + xattn_kernel + token_block kernel") if o.fused_block
                         else "GEMM / attention_kernel launches",
         "self_attention": "sattn_kernel (q.k^T + softmax + P.v per (cloud, head))" if (o.self_attn and fused) else "batched GEMMs",
         "fine_match": "finematch.hip pipeline (E written once, read twice)" if (bool(cfg.get("fused_fine", o.fused_fine)) and o.fused_block)

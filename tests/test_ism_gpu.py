@@ -206,6 +206,13 @@ def test_ism_proposals_sharded_equals_unsharded_on_one_gpu(dev, quirk):
     r = score_fn(torch.arange(200, device=dev))
     assert r["all_positive"] == (not quirk)
     fin = ism.final_score(r["sem"], r["appe"], r["iou"], r["vis"])
+    # the same with the quirk decided on the device (no host read-back between IoU and final score)
+    sim_all = ism.pairwise_similarity(g["q"], g["ref"])
+    sel_a, obj_a, sem_a, best_a = ism.semantic_select(sim_all, "avg_5", 0.2)
+    _, xyxy_a, _ = ism.project_template_to_image(best_a, obj_a, g["poses"], g["pc"], masks, g["depth"], g["K"], g["depth_scale"], mask_index=sel_a)
+    iou_d, flag = ism.compute_iou(xyxy_a, boxes[sel_a], return_flag=True)
+    assert int(flag.item()) == (0 if quirk else 1)
+    assert torch.equal(ism.final_score(r["sem"], r["appe"], iou_d, r["vis"], all_positive=flag), fin)
     keep = ism.nms(r["boxes"].float(), fin, 0.25, object_ids=r["object_ids"])
     want = dict(scores=fin[keep], object_ids=r["object_ids"][keep], boxes=r["boxes"][keep], proposal_ids=r["sel"][keep])
     assert 0 < len(keep) < len(r["sel"]) < 200
