@@ -289,7 +289,11 @@ int sam6d_linattn_focus_q(float* q, const float* scale, const float* ksum, int B
 /* PositionalEncoding, one scale (PEM/model/fine_point_matching.py:126-139): QueryAndGroup
  * (PEM/model/pointnet2/pointnet2_utils.py:383-396) + SharedMLP 6->32->64->128 with eval BatchNorm folded to per-channel
  * scale/shift (PEM/model/pointnet2/pytorch_utils.py:25-50) + max over the ball, fused.  idx (B,N,S) from sam6d_ball_query
- * with new_xyz = pts + 1e-8; writes out[(b*N+j)*ldo + off + c], c < 128.  S must be a multiple of 32. */
+ * with new_xyz = pts + 1e-8; writes out[(b*N+j)*ldo + off + c], c < 128.  S must be a multiple of 32.
+ * Range (split-precision mode): the six input features of a neighbour are scaled by a power of two chosen per neighbour, so layer 1
+ * is accurate for coordinates of any magnitude; the hidden activations of layers 2 / 3 are split into fp16 halves unscaled and must
+ * stay below 65504 -- coordinates below ~1e4 for weights of order one (PEM encodes radius-normalised clouds, |x| < 10).  Matmul mode 0
+ * (exact fp32) has no such limit. */
 int sam6d_pe_mlp_max(const float* pts, const int* idx, int B, int N, int S, const float* W1, const float* sc1,
                      const float* sh1, const float* W2, const float* sc2, const float* sh2, const float* W3,
                      const float* sc3, const float* sh3, float* out, long ldo, int off, void* stream);

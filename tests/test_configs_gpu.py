@@ -483,7 +483,10 @@ def test_weight_guard_fallback_routes_end_to_end_vs_oracle(dev, sd, case):
     else:
         assert paths["fused_rpe_guard_passed"] is False and "exact fp32" in paths["embedding_rows"], paths
     B = 2
-    inp = synth.config2_inputs(B=B, seed=23)
+    # (seed 1: the benchmark's generator.  Seed 23 was tried first and has, in proposal 1, two scene points at bitwise the same distance
+    #  from a third: torch.topk's tie order is unspecified and differs from the lowest-index rule here, which moves that proposal's
+    #  attention by 1e-2 on EVERY route, the default one included -- scratch/dbg_fallback.py)
+    inp = synth.config2_inputs(B=B, seed=1)
     d = {k: v.to(dev) for k, v in inp.items()}
     keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
     oR0, ot0, oR, ot, os_ = [], [], [], [], []
