@@ -66,6 +66,9 @@ __global__ __launch_bounds__(256) void fm_prep_kernel(const float* __restrict__ 
 // (Measured and removed, round 3: staging by LDS-DMA -- 1 KiB pieces of 16 rows x 64 B with a per-lane swizzled source chunk so that the
 // linear LDS image is conflict-free, two 32 KB slots, one barrier per chunk: the whole fine match 0.575 ms against 0.551 ms; two
 // workgroups per CU instead of three to four, and eight DMA pieces of ~45 issue cycles per wave and chunk.)
+// (Measured and removed, round 4: 256 x 128 tiles -- eight waves in a 4 x 2 grid, 70 KB of dynamic LDS, a quarter less operand traffic from
+// the L2 per output.  At 128 registers (two workgroups per CU) the kernel spills 9 VGPRs, at 151 only one
+// workgroup of eight waves fits a CU; bit-identical results, the fine-match pipeline 0.592 ms against 0.537 ms with the 128 x 128 tile.)
 #define FM_BK 32
 #define FM_LD 40  // halves per LDS row (80 B): the ds_read_b128 fragment reads of 16 consecutive rows are conflict-free
 __global__ __launch_bounds__(256) void fm_sim_kernel(const _Float16* __restrict__ fh, const _Float16* __restrict__ fl, int B,
