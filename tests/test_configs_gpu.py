@@ -506,3 +506,35 @@ def test_weight_guard_fallback_routes_end_to_end_vs_oracle(dev, sd, case):
     print("\n%s: coarse attention %.2e; fine stage from the oracle's coarse pose: dR %.2e dt %.2e ds %.2e"
           % (case, worst, _d(R2, torch.cat(oR)), _d(t2, torch.cat(ot)), _d(s2, torch.cat(os_))))
     _close(R2, torch.cat(oR), 1e-4, case + ": R"); _close(t2, torch.cat(ot), 1e-4, case + ": t"); _close(s2, torch.cat(os_), 1e-4, case + ": score")
+
+
+# ------------------------------------------------------------------------------------------------------------ hipGraph replay
+def test_pem_graph_replay_equals_eager(dev, W):
+    """pem.PemGraph: one pem_match launch sequence captured into a hipGraph.  A replay on new inputs (copied into the graph's static
+    buffers) is bit for bit the eager call -- plain batch, micro-batch slices on concurrent streams of the graph (flat forks: the only
+    shape the capture produces), and a multi-object batch with template_ids fixed at capture."""
+    from sam6d_hip import pem, synth
+    keys = ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")
+    a = {k: v.to(dev) for k, v in synth.config2_inputs(B=16, seed=31).items()}
+    b = {k: v.to(dev) for k, v in synth.config2_inputs(B=16, seed=32).items()}
+    want_a = [o.clone() for o in pem.pem_match(*[a[k] for k in keys], W, a["rand"])]
+    want_b = [o.clone() for o in pem.pem_match(*[b[k] for k in keys], W, b["rand"])]
+    for mb in (1, 2):
+        g = pem.PemGraph(W, *[a[k] for k in keys], a["rand"], microbatch=mb)
+        out = g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(out, want_a)), "replay on the capture inputs, microbatch %d" % mb
+        out = g(*[b[k] for k in keys], b["rand"])
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(out, want_b)), "replay on new inputs, microbatch %d" % mb
+        with pytest.raises(ValueError):
+            g(*[b[k][:8] for k in keys], b["rand"][:8])
+        del g
+    c = {k: v.to(dev) for k, v in synth.config4_inputs(B=12, n_obj=4, seed=33).items()}
+    want_c = [o.clone() for o in pem.pem_match(*[c[k] for k in keys], W, c["rand"], template_ids=c["template_ids"])]
+    g = pem.PemGraph(W, *[c[k] for k in keys], c["rand"], template_ids=c["template_ids"])
+    out = g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(out, want_c))
+    with pytest.raises(ValueError):
+        pem.PemGraph(W, *[c[k] for k in keys], c["rand"], template_ids=c["template_ids"] + 4)
