@@ -10,6 +10,7 @@ Citations: PEM = SAM-6D/Pose_Estimation_Model in the reference.
 """
 import math
 import os
+import threading
 
 import torch
 
@@ -109,14 +110,21 @@ class Options:
         return {k: getattr(self, k) for k in self.DEFAULTS if k != "matmul_mode"} | {"matmul_mode": self.mode}
 
 
-_FLAGS = None
-_DEPTH = 0
+class _Tls(threading.local):
+    """Per-thread state of the entry points: the Options of the outermost call in flight, its nesting depth and the micro-batch pipeline
+    slot -- the library's matmul mode is per thread too (sam6d_set_thread_matmul_mode), so two threads may drive two models at once."""
+    flags = None
+    depth = 0
+    pipe = None
+
+
+_TLS = _Tls()
 
 
 def _flags():
     """Inside a public entry point (on_tensor_device): the Options it was entered with; outside: the environment's, read afresh."""
-    if _FLAGS is not None:
-        return _FLAGS
+    if _TLS.flags is not None:
+        return _TLS.flags
     return Options.from_env()
 
 
@@ -140,24 +148,23 @@ def on_tensor_device(fn):
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
-        global _DEPTH, _FLAGS
         dev = next((a.device for a in args if torch.is_tensor(a)), None)
         if dev is None or dev.type != "cuda":
             raise RuntimeError("%s: needs HIP device tensors (this build has no CPU path)" % fn.__name__)
         opts = _find_options(args, kwargs)
-        outer = _DEPTH == 0
+        outer = _TLS.depth == 0
         if outer:
-            _FLAGS = opts if opts is not None else Options.from_env()
+            _TLS.flags = opts if opts is not None else Options.from_env()
             prev_mode = int(_lib.load().sam6d_get_thread_matmul_mode())
-            _lib.call("sam6d_set_thread_matmul_mode", _FLAGS.mode)
-        _DEPTH += 1
+            _lib.call("sam6d_set_thread_matmul_mode", _TLS.flags.mode)
+        _TLS.depth += 1
         try:
             with torch.cuda.device(dev):
                 return fn(*args, **kwargs)
         finally:
-            _DEPTH -= 1
+            _TLS.depth -= 1
             if outer:
-                _FLAGS = None
+                _TLS.flags = None
                 _lib.call("sam6d_set_thread_matmul_mode", prev_mode)
     return wrapper
 
@@ -536,8 +543,7 @@ PROFILE_NAMES = None
 # another slice's throughput-bound kernel, so the big kernels take turns: occurrence k of a big kernel in slice s waits for occurrence k
 # of the same kernel in slice s - 1 (an event recorded earlier in program order: slices are issued one after the other).  Slice 0 runs
 # free, slice 1 trails it by one big kernel, and so on: at any time at most one slice is inside a given big kernel while the others are
-# in their latency-bound stretches.  _PIPE = (events, slice index, per-slice occurrence counters) while a slice is being issued.
-_PIPE = None
+# in their latency-bound stretches.  _TLS.pipe = (events, slice index, per-slice occurrence counters) while a slice is being issued.
 _BIG = frozenset(("rpe_score_kernel", "linattn_layer", "score_hyp", "fine_match", "linear_norm_split", "pe_mlp", "gemm_big"))
 
 
@@ -548,8 +554,8 @@ class _Timed:
     def __enter__(self):
         self.on = PROFILE is not None and (PROFILE_NAMES is None or self.name in PROFILE_NAMES)
         self.turn = None
-        if _PIPE is not None and self.name in _BIG:
-            ev, s, counts = _PIPE
+        if _TLS.pipe is not None and self.name in _BIG:
+            ev, s, counts = _TLS.pipe
             k = counts.get(self.name, 0)
             counts[self.name] = k + 1
             self.turn = (s, self.name, k)
@@ -566,10 +572,10 @@ class _Timed:
         if self.on:
             self.b.record()
             PROFILE.setdefault(self.name, []).append((self.a, self.b))
-        if self.turn is not None and _PIPE is not None:
+        if self.turn is not None and _TLS.pipe is not None:
             e = torch.cuda.Event()
             e.record(torch.cuda.current_stream())
-            _PIPE[0][self.turn] = e
+            _TLS.pipe[0][self.turn] = e
 
 
 @on_tensor_device
@@ -1621,19 +1627,18 @@ def pem_match(dense_pm, dense_fm, dense_po, dense_fo, radius, model, W, rand, cf
     serial_prep = bool(cfg.get("mb_serial_prepare", False))
     preps = [prepare(lo, hi) for lo, hi in spans] if serial_prep else [None] * len(spans)
     outs = []
-    global _PIPE
     events = {}
     for i, (lo, hi) in enumerate(spans):
         st = _side_stream(dense_pm.device, ("mb", i))
         st.wait_stream(main)
-        _PIPE = (events, i, {}) if cfg.get("mb_pipeline", True) else None
+        _TLS.pipe = (events, i, {}) if cfg.get("mb_pipeline", False) else None
         try:
             with torch.cuda.stream(st):
                 if preps[i] is None:
                     preps[i] = prepare(lo, hi)
                 outs.append(rest(preps[i], lo, hi, ("mb", i, "side")))
         finally:
-            _PIPE = None
+            _TLS.pipe = None
         if serial_prep:
             for tns in preps[i][:5]:
                 for x in (tns if isinstance(tns, tuple) else (tns,)):

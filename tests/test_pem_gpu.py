@@ -910,6 +910,38 @@ def test_two_weight_sets_with_different_arithmetic_in_one_process(dev, sd):
     assert _lib.load().sam6d_get_thread_matmul_mode() == -1
 
 
+def test_two_threads_two_arithmetic_modes(dev, sd):
+    """The entry points keep their state (Options in flight, nesting depth) per THREAD and the library its matmul mode per thread: two
+    Python threads driving a split-precision and an exact-fp32 weight set at the same time each get what they get alone."""
+    import threading
+    from sam6d_hip import _lib, pem, synth
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("needs the default (fp16x3) process mode")
+    inp = synth.config2_inputs(B=2, seed=22)
+    d = {k: v.to(dev).contiguous() for k, v in inp.items()}
+    args = [d[k] for k in ("dense_pm", "dense_fm", "dense_po", "dense_fo", "radius", "model")]
+    Ws = [pem.PemWeights(sd, dev, options=pem.Options(matmul_mode=1)), pem.PemWeights(sd, dev, options=pem.Options(matmul_mode=0))]
+    alone = [[o.cpu() for o in pem.pem_match(*args, Wx, d["rand"])] for Wx in Ws]
+    got, errs = [[], []], []
+
+    def work(i):
+        try:
+            with torch.cuda.device(dev):
+                for _ in range(4):
+                    got[i].append([o.cpu() for o in pem.pem_match(*args, Ws[i], d["rand"])])
+        except Exception as e:  # surfaced in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(2):
+        for res in got[i]:
+            assert all(torch.equal(x, y) for x, y in zip(res, alone[i])), "thread %d: result differs from the single-threaded run" % i
+    assert _lib.load().sam6d_get_thread_matmul_mode() == -1
+
+
 def test_pem_match_repeatable_with_side_stream(dev, W):
     """The default pipeline (one batch, pose-independent fine work on a side stream) must reproduce the serial result bit for
     bit, run after run (the micro-batch mode has its own invariance test; both have been bit-stable since the library is built
