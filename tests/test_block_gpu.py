@@ -354,6 +354,8 @@ def test_rows_linear_vs_fp64(dev, clouds, rpb, N, xs):
     """sam6d_rows_linear: y = x W^T + b for the token rows of a buffer with a skipped bg slot on the input side and on the output side
     (the sparse-token projections; PEM/model/coarse_point_matching.py:35-38, PEM/model/transformer.py:556-558) against float64."""
     from sam6d_hip import _lib, pem
+    if _lib.load().sam6d_get_matmul_mode() == 0:
+        pytest.skip("the panel kernel serves the split-precision modes (matmul mode 0 routes these projections to the exact GEMM)")
     gen = torch.Generator().manual_seed(clouds * 1000 + rpb + N)
     w = (torch.rand(N, 256, generator=gen) * 2 - 1) / 16
     b = (torch.rand(N, generator=gen) * 2 - 1) * xs

@@ -462,7 +462,9 @@ def test_weight_guard_fallback_routes_end_to_end_vs_oracle(dev, sd, case):
     attention_kernel<RPE>) or of the split-precision embedding images altogether (s = 4000: the exact fp32 embedding kernel).
     three_product_stage1: sigma_a = 7.5 doubles the angular index range, for which the host check refuses the two-product form."""
     from oracle import pem_oracle as O
-    from sam6d_hip import pem, synth
+    from sam6d_hip import _lib, pem, synth
+    if _lib.load().sam6d_get_matmul_mode() != 1:
+        pytest.skip("the guards choose between routes of the default (fp16x3) arithmetic")
     sd2 = dict(sd)
     cfg, ocfg = dict(pem.DEFAULT_CFG), dict(O.DEFAULT_CFG)
     if case == "three_product_stage1":
@@ -474,7 +476,7 @@ def test_weight_guard_fallback_routes_end_to_end_vs_oracle(dev, sd, case):
                 sd2[k] = sd[k] * s_
             elif k.endswith("attention.proj_p.weight"):
                 sd2[k] = sd[k] / s_
-    W2 = pem.PemWeights(sd2, dev)
+    W2 = pem.PemWeights(sd2, dev, options=pem.Options())  # the default routes, whatever A/B switches the environment carries
     paths = pem.describe_paths(W2, cfg)
     if case == "three_product_stage1":
         assert paths["rpe_stage1_products"] == 3, paths

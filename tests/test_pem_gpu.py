@@ -614,7 +614,8 @@ def test_pem_end_to_end_vs_reference(dev, W, tag, kernels):
     g = golden("pem_e2e")
     inp = synth.kat_inputs(B=2, seed=int(g["kat_seed"])) if tag == "kat" else synth.config2_inputs(B=2, seed=int(g["cfg2_seed"]))
     d = _to(dev, inp)
-    cfg = pem.DEFAULT_CFG if kernels == "default" else dict(pem.DEFAULT_CFG, fused_rpe=False, fused_fine=False)
+    # (explicit cfg keys: they win over the SAM6D_FUSED_* environment switches an A/B run of the suite may carry)
+    cfg = dict(pem.DEFAULT_CFG, fused_rpe=(kernels == "default"), fused_fine=(kernels == "default"))
     R, t, s, aux = pem.pem_match(d["dense_pm"], d["dense_fm"], d["dense_po"], d["dense_fo"], d["radius"], d["model"], W,
                                  d["rand"], cfg=cfg, return_aux=True)
     torch.cuda.synchronize()
