@@ -309,9 +309,55 @@ def mask_to_rle(masks):
     return [{"counts": c[o[i]:o[i + 1]], "size": [H, W]} for i in range(len(o) - 1)]
 
 
+def rle_string_to_counts(s):
+    """The counts of a pycocotools COMPRESSED RLE string (cocoapi maskApi.c rleFrString): 5-bit groups, least significant first, + 48 per
+    character, bit 5 = continuation, bit 4 of the last group = sign; counts from the third on are differences to the count two places
+    before.  Host-side text decoding (a few hundred characters per mask); the runs are expanded on the device (rle_to_mask)."""
+    if isinstance(s, bytes):
+        s = s.decode("ascii")
+    counts, p, n = [], 0, len(s)
+    while p < n:
+        x, k, more = 0, 0, True
+        while more:
+            if p >= n:
+                raise RuntimeError("rle_string_to_counts: truncated string")
+            g = ord(s[p]) - 48
+            if g < 0 or g > 63:
+                raise RuntimeError("rle_string_to_counts: character %r is outside the RLE alphabet" % s[p])
+            x |= (g & 0x1F) << (5 * k)
+            more = bool(g & 0x20)
+            p += 1
+            k += 1
+            if not more and (g & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        if x < 0:
+            raise RuntimeError("rle_string_to_counts: negative run length")
+        counts.append(x)
+    return counts
+
+
+def rle_counts_to_string(counts):
+    """Inverse of rle_string_to_counts (cocoapi maskApi.c rleToString)."""
+    out = []
+    for i, c in enumerate(counts):
+        x = int(c) - (int(counts[i - 2]) if i > 2 else 0)
+        more = True
+        while more:
+            g = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (g & 0x10) else (x != 0)
+            if more:
+                g |= 0x20
+            out.append(chr(g + 48))
+    return "".join(out)
+
+
 def rle_to_mask(rles, device):
-    """Inverse of mask_to_rle for a list of uncompressed RLE dicts of one size -> (N,H,W) uint8 on `device` (what
-    cocomask.decode returns in PEM/run_inference_custom_pytorch.py:312-317)."""
+    """Inverse of mask_to_rle for a list of RLE dicts of one size -> (N,H,W) uint8 on `device` (what cocomask.decode returns in
+    PEM/run_inference_custom_pytorch.py:312-317): uncompressed counts lists as the ISM side writes them, or pycocotools' compressed
+    counts strings (the form `rle = seg` takes there when frPyObjects refuses the object)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("rle_to_mask: needs a HIP device (no CPU path)")
@@ -322,9 +368,8 @@ def rle_to_mask(rles, device):
     for r in rles:
         if [int(v) for v in r["size"]] != [H, W]:
             raise RuntimeError("rle_to_mask: all masks must have one size")
-        if isinstance(r["counts"], (str, bytes)):
-            raise RuntimeError("rle_to_mask: compressed RLE strings are pycocotools' own format; only uncompressed counts are read")
-        flat.extend(int(v) for v in r["counts"])
+        c = rle_string_to_counts(r["counts"]) if isinstance(r["counts"], (str, bytes)) else r["counts"]
+        flat.extend(int(v) for v in c)
         offs.append(len(flat))
     N = len(rles)
     with torch.cuda.device(device):

@@ -222,6 +222,48 @@ def rle_to_mask(rle):
     return out.reshape(w, h).transpose()
 
 
+def rle_counts_to_string(counts):
+    """pycocotools' COMPRESSED counts string (`rleToString`, cocoapi common/maskApi.c, pycocotools 2.0.x -- the package is NOT installed
+    here and the reference checkout holds no such string: PARITY UNPINNED, restated from the published algorithm and pinned only by
+    hand-worked strings in tests/test_oracle_golden.py).  Every count from the third on is stored as the difference to the count two
+    places before; each value is written in 5-bit groups, least significant first, bit 5 = "more groups follow", bit 4 of the last
+    group = the sign; every group + 48 is one ASCII character."""
+    out = []
+    for i, c in enumerate(counts):
+        x = int(c) - (int(counts[i - 2]) if i > 2 else 0)
+        more = True
+        while more:
+            g = x & 0x1F
+            x >>= 5  # arithmetic shift
+            more = (x != -1) if (g & 0x10) else (x != 0)
+            if more:
+                g |= 0x20
+            out.append(chr(g + 48))
+    return "".join(out)
+
+
+def rle_counts_from_string(s):
+    """Inverse of rle_counts_to_string (`rleFrString`, same source; what cocomask.decode does first with the string form that
+    PEM/run_inference_custom_pytorch.py:312-317 falls back to when `frPyObjects` refuses the object)."""
+    if isinstance(s, bytes):
+        s = s.decode("ascii")
+    counts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            g = ord(s[p]) - 48
+            x |= (g & 0x1F) << (5 * k)
+            more = bool(g & 0x20)
+            p += 1
+            k += 1
+            if not more and (g & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return counts
+
+
 def xyxy_to_xywh(bbox):
     """ISM/utils/bbox_utils.py:129-138 (the 2-D branch has no +1; the 1-D branch has)."""
     bbox = np.asarray(bbox)

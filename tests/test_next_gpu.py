@@ -307,7 +307,7 @@ def test_mask_rle_rejects_cpu_and_bad_offsets(dev):
     with pytest.raises(RuntimeError):
         ism.mask_rle_encode(torch.zeros(1, 4, 4))
     with pytest.raises(RuntimeError):
-        ism.rle_to_mask([{"counts": "abc", "size": [2, 2]}], dev)
+        ism.rle_to_mask([{"counts": "ab\x01", "size": [2, 2]}], dev)  # a character outside the RLE alphabet
     m = torch.zeros(1, 4, 4, device=dev); m[0, 1, 1] = 1
     counts = torch.full((8,), -5, dtype=torch.int32, device=dev)
     offs = torch.tensor([0, 5], dtype=torch.int64, device=dev)  # the mask has 3 runs, not 5: nothing may be written
@@ -353,3 +353,28 @@ def test_detection_ism_json_seam(dev, tmp_path):
     assert U.mask_to_rle(masks[3].numpy()) == want[3]["segmentation"]
     again = U.Detections(path + ".npz")  # load_from_file: xywh -> xyxy, ids back to 0-based
     assert np.array_equal(again.object_ids, oids.numpy()) and np.array_equal(np.asarray(again.masks), masks.numpy())
+
+
+def test_compressed_rle_strings_decode_like_their_counts(dev):
+    """pycocotools' COMPRESSED counts strings (the form PEM/run_inference_custom_pytorch.py:312-317 passes to cocomask.decode when
+    frPyObjects refuses the object): the string of a mask's runs decodes to the same mask as the uncompressed runs, for seeded masks,
+    an empty and a full mask; encode -> decode round trip of the strings.  PARITY UNPINNED (pycocotools is not installed; the codec is
+    restated from cocoapi's maskApi.c and pinned by hand-worked strings in tests/test_oracle_golden.py)."""
+    from sam6d_hip import ism
+    gen = torch.Generator().manual_seed(12)
+    masks = (torch.rand(6, 40, 56, generator=gen) > 0.55).float()
+    masks[1, 5:30, 10:50] = 1.0
+    masks[2] = 0.0
+    masks[3] = 1.0
+    rles = ism.mask_to_rle(masks.to(dev))
+    strs = [{"counts": ism.rle_counts_to_string(r["counts"]), "size": r["size"]} for r in rles]
+    for r, q in zip(rles, strs):
+        assert ism.rle_string_to_counts(q["counts"]) == r["counts"]
+        assert ism.rle_string_to_counts(q["counts"].encode("ascii")) == r["counts"]
+    a = ism.rle_to_mask(rles, dev)
+    b = ism.rle_to_mask(strs, dev)
+    c = ism.rle_to_mask([rles[0], strs[1], strs[2], rles[3], strs[4], rles[5]], dev)  # both forms in one file
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert np.array_equal(a.cpu().numpy().astype(bool), masks.numpy() > 0)
+    with pytest.raises(RuntimeError):
+        ism.rle_string_to_counts("T")  # continuation bit set on the last character

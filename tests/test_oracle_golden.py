@@ -406,3 +406,22 @@ def test_detection_records_format():
     assert json.loads(json.dumps(rec)) == rec
     lmo = IO.detections_to_records(np.array([1, 7]), np.array([0.1, 0.2]), np.array([[0, 0, 1, 1], [0, 0, 1, 1]]), masks, dataset_name="lmo")
     assert [r["category_id"] for r in lmo] == [5, 12]
+
+
+def test_compressed_rle_string_codec_known_answers():
+    """pycocotools' compressed counts strings, restated (PARITY UNPINNED: the package is absent): hand-worked strings.  A value is
+    written in 5-bit groups, least significant first, each + 48; bit 5 = another group follows; bit 4 of the last group = sign:
+      0 -> '0'; 5 -> '5'; 15 -> '?' (0x0f + 48); 16: its first group 0x10 has bit 4 set although the value is positive, so a second
+      group (0) must follow: chr(0x30 + 48) then '0'; 100 = 3 * 32 + 4 -> groups 4 (more), 3 -> 'T3';
+      counts from the third on are stored as differences to the count two places before: [0, 5, 7, 5] -> '0', '5', '7', then 5 - 5 = 0 -> '0'."""
+    enc, dec = IO.rle_counts_to_string, IO.rle_counts_from_string
+    assert enc([0]) == "0" and enc([5]) == "5" and enc([15]) == "?"
+    assert enc([100]) == "T3"                       # 4 | 0x20 -> 36 + 48 = 'T'; then 3 -> '3'
+    assert enc([16]) == chr(0x30 + 48) + "0"        # group 0x10 has the sign bit set and x is not -1: continue (| 0x20), then 0
+    assert enc([0, 5, 7, 5]) == "0570"
+    assert enc([0, 5, 7, 3]) == "057" + chr((-2 & 0x1F) + 48)   # 3 - 5 = -2 -> one group 0b11110 (sign bit set, x becomes -1: stop)
+    for counts in ([0, 5, 7, 5], [3, 1, 4, 1, 5, 9, 2, 6], [307200], [0, 307200], [1000, 2000, 1, 70000, 31, 32, 33]):
+        assert dec(enc(counts)) == counts
+    from sam6d_hip import ism
+    for counts in ([0, 5, 7, 3], [12345, 1, 2, 3, 40000]):
+        assert ism.rle_counts_to_string(counts) == enc(counts) and ism.rle_string_to_counts(enc(counts)) == counts
