@@ -1222,6 +1222,14 @@ __global__ __launch_bounds__((4 + LOADERS) * 64, LOADERS ? 1 : 2) void out_split
   }
 }
 
+// (Measured and removed, round 4: the same pass as a PERSISTENT kernel -- one workgroup per CU, four computing + four loader waves, the
+// loader waves streaming the eight panels round and round without a bubble at the tile seams, each computing wave requesting the NEXT
+// tile's rows right after splitting the current ones (no LDS-DMA in the computing waves' vector-memory queue, so nothing orders the row
+// loads behind a panel wait).  Same bits; 117.5 / 117.9 us against 111.8 us per launch at M = 131 136 (scratch/ub_stream.py).  The row
+// latency was not the bound: every 64-row tile re-streams the 256 KB weight image through the LDS-DMA path, 2048 tiles x 256 KB = 537 MB
+// per launch at ~18 GB/s per CU (4.6 TB/s chip-wide) -- the pass moves twice as many weight bytes L2 -> LDS as token bytes HBM -> registers.
+// Fewer weight bytes per row need wider row tiles (128 rows on eight computing waves without loader waves) or resident weights (256 KB
+// of fp16 hi / lo do not fit the 160 KB of LDS; half the output channels do, but the row norm needs all 256).)
 extern "C" int sam6d_linear_norm_split(const float* x, const void* wimage, const float* bias, float inv_w_scale, void* fh, void* fl,
                                        long M, void* stream) {
   SAM6D_REQUIRE(x && wimage && bias && fh && fl && M >= 0 && inv_w_scale > 0.f, "linear_norm_split: bad arguments");
