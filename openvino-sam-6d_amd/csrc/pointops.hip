@@ -15,22 +15,62 @@
 // Farthest point sampling.
 // One workgroup per cloud (the selection is sequential in j).  Points live in LDS (for the broadcast of the last
 // selected point) and each thread keeps its PPT points + running min-distance in registers.  Per round:
-// PPT distance updates -> thread-local arg-max -> wave64 butterfly on a packed 64-bit key -> one LDS slot per wave
-// -> one barrier -> every thread reduces the NW wave slots.
+// PPT distance updates -> thread-local arg-max -> wave reduction -> one LDS slot per wave -> one barrier -> every thread reduces the
+// NW wave slots.
 //
-// Key packing: d2 >= +0 so its bit pattern is monotone; key = bits(d2) << 32 | ~idx  => max key = max distance,
-// lowest index on ties  == the reference's strict `d2 > best` scan in increasing k (sampling.cpp:105-111).
+// Selection rule: max distance, lowest index on ties == the reference's strict `d2 > best` scan in increasing k (sampling.cpp:105-111).
+// (fps_big_kernel / fps_grid_kernel pack it into one 64-bit key: d2 >= +0 so its bit pattern is monotone; key = bits(d2) << 32 | ~idx.)
 // Points inside the origin ball (mag <= 1e-3, compared in double like the reference, sampling.cpp:102-103) never
-// compete and keep temp = FLT_MAX; their key is 0.  If every point is skipped the result is index 0, as in the
+// compete and keep temp = FLT_MAX (key 0 / candidate distance -1).  If every point is skipped the result is index 0, as in the
 // reference (besti initialised to 0).
 // =========================================================================================================
+// max reductions for the sampling rounds as single instructions (v_max_f32_dpp; the compiler's form of the same DPP step is a
+// v_mov 0, the DPP move, a canonicalising v_max and the v_max: the rounds are bound by instructions issued per round)
+template <int ROR>
+__device__ __forceinline__ float fps_max_ror(float x) {
+  float r;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(ROR));
+  return r;
+}
+__device__ __forceinline__ float fps_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float fps_row_max(float v) {  // every lane: the maximum of its 16-lane row
+  v = fps_max_ror<8>(v);
+  v = fps_max_ror<4>(v);
+  v = fps_max_ror<2>(v);
+  return fps_max_ror<1>(v);
+}
+__device__ __forceinline__ float fps_wave_max(float v) {
+  typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+  v = fps_row_max(v);
+  // swap of two copies: one result holds the even rows' (lower half's) value in both rows of a pair, the other the odd rows' (upper half's)
+  u2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fps_vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fps_vmax(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float fps_uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+// Round 4: a round is one serial chain (barrier -> best of the wave slots -> distances -> wave reduction -> slot) that every wave
+// executes, so the kernel's time is 196 x (instructions per round x waves per SIMD x 4 cycles + the LDS / barrier latencies).  Lane t
+// owns the PPT CONSECUTIVE points t PPT .. t PPT + PPT - 1, so inside a wave and across the waves a lower lane / wave means a lower
+// index: the wave's winner is the lowest lane that holds the wave maximum (one DPP / permlane max reduction, a ballot and four
+// v_readlane instead of six ds_bpermute steps on a 64-bit key), the round's winner the lowest slot that holds the maximum of the slots
+// (lane l reads slot l, a 16-lane DPP maximum, a ballot, v_readlane), and a slot carries the winner's coordinates, so the next round does
+// not start with a second, dependent LDS read of the point.  Same selection rule: the largest running min-distance, ties to the
+// smallest index (sampling.cpp:96-126).
 template <int THREADS, int PPT>
 __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restrict__ xyz, int N, int m,
                                                          int* __restrict__ out) {
   extern __shared__ float smem[];  // [N*3] points, then wave slots
   constexpr int NW = THREADS / 64;
+  static_assert(NW <= 16, "one slot per lane of a 16-lane row");
   float* sp = smem;
-  unsigned long long* slots = reinterpret_cast<unsigned long long*>(smem + ((N * 3 + 3) & ~3));  // [2][NW]
+  float4* slots = reinterpret_cast<float4*>(smem + ((N * 3 + 3) & ~3));  // [2][NW] {d, x, y, z}
+  int* slotk = reinterpret_cast<int*>(slots + 2 * NW);                    // [2][NW] index
 
   const int b = blockIdx.x;
   const int t = threadIdx.x;
@@ -44,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
   bool live[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = t + i * THREADS;
+    const int k = t * PPT + i;
     if (k < N) {
       px[i] = sp[k * 3 + 0];
       py[i] = sp[k * 3 + 1];
@@ -58,33 +98,48 @@ __global__ __launch_bounds__(THREADS) void fps_reg_kernel(const float* __restric
     td[i] = FLT_MAX;
   }
   if (t == 0) o[0] = 0;
-  int last = 0;
+  const float x0 = fps_uniform(sp[0]), y0 = fps_uniform(sp[1]), z0 = fps_uniform(sp[2]);
+  float x1 = x0, y1 = y0, z1 = z0;  // the last selected point (wave-uniform: scalar registers)
   for (int j = 1; j < m; ++j) {
-    const float x1 = sp[last * 3 + 0], y1 = sp[last * 3 + 1], z1 = sp[last * 3 + 2];
-    unsigned long long key = 0ull;
+    // this lane's candidate: the largest min-distance of its live points, the first on a tie; -1: no live point (selects, no branches)
+    float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+    int bk = 0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      if (live[i]) {
-        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
-        const float d2 = (td[i] < d) ? td[i] : d;
-        td[i] = d2;
-        const unsigned int k = (unsigned int)(t + i * THREADS);
-        const unsigned long long kk = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(~k);
-        key = kk > key ? kk : key;
-      }
+      const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const float d2 = (td[i] < d) ? td[i] : d;
+      td[i] = live[i] ? d2 : td[i];
+      const bool take = live[i] & (d2 > bd);
+      bd = take ? d2 : bd;
+      bk = take ? t * PPT + i : bk;
+      bx = take ? px[i] : bx;
+      by = take ? py[i] : by;
+      bz = take ? pz[i] : bz;
     }
-    key = wave_max_u64(key);
-    unsigned long long* sl = slots + (j & 1) * NW;
-    if ((t & 63) == 0) sl[t >> 6] = key;
+    const float wm = fps_wave_max(bd);
+    const int wl = __ffsll((long long)__ballot(bd == wm)) - 1;  // lowest lane with the wave maximum = lowest index
+    float4* sl = slots + (j & 1) * NW;
+    int* sk = slotk + (j & 1) * NW;
+    if ((t & 63) == wl) {
+      sl[t >> 6] = make_float4(bd, bx, by, bz);
+      sk[t >> 6] = bk;
+    }
     __syncthreads();
-    unsigned long long best = sl[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) {
-      const unsigned long long v = sl[w];
-      best = v > best ? v : best;
-    }
-    last = (best == 0ull) ? 0 : (int)(~(unsigned int)(best & 0xffffffffull));
+    const float4 sv = sl[t & (NW - 1)];  // lane l of every 16-lane row: slot l mod NW
+    int kv = sk[t & (NW - 1)];
+    asm volatile("" : "+v"(kv));  // (both slot reads issued together: the index is not read behind a branch on the maximum)
+    const float best = fps_row_max(sv.x);
+    const int rl = __ffsll((long long)__ballot(sv.x == best)) - 1;  // lowest slot with the maximum (lanes 0 .. NW-1 come first)
+    const bool none = fps_uniform(best) < 0.f;  // every point skipped: index 0, as in the reference (besti initialised to 0)
+    int rk = __builtin_amdgcn_readlane(kv, rl);
+    unsigned rx = __builtin_amdgcn_readlane(__float_as_uint(sv.y), rl), ry = __builtin_amdgcn_readlane(__float_as_uint(sv.z), rl),
+             rz = __builtin_amdgcn_readlane(__float_as_uint(sv.w), rl);
+    asm volatile("" : "+s"(rk), "+s"(rx), "+s"(ry), "+s"(rz));
+    const int last = none ? 0 : rk;
+    x1 = none ? x0 : __uint_as_float(rx);
+    y1 = none ? y0 : __uint_as_float(ry);
+    z1 = none ? z0 : __uint_as_float(rz);
     if (t == 0) o[j] = last;
   }
 }
@@ -253,8 +308,9 @@ extern "C" int sam6d_furthest_point_sampling(const float* xyz, int B, int N, int
   SAM6D_REQUIRE(B >= 0 && N > 0 && m >= 0, "furthest_point_sampling: bad sizes B=%d N=%d m=%d", B, N, m);
   if (B == 0 || m == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)((N * 3 + 3) & ~3) * 4 + 2 * 16 * 8;
-  if (N <= 512 * 4) {  // (256 threads x 8 points per lane -- 4 waves, a cheaper barrier -- was measured: 179 us against 160 us)
+  const size_t lds = (size_t)((N * 3 + 3) & ~3) * 4 + 2 * 16 * (16 + 4);
+  if (N <= 512 * 4) {  // (round 4, 64 clouds x 2048 -> 196: 108 us; 256 threads x 8 points per lane -- one wave per SIMD -- 144 us; round 3's
+                       //  butterfly on a 64-bit key 161 us)
     hipLaunchKernelGGL((fps_reg_kernel<512, 4>), dim3(B), dim3(512), lds, s, xyz, N, m, idx);
   } else if (N <= 1024 * 4) {  // 48 KB of LDS points: stays under the 64 KB dynamic-LDS default
     hipLaunchKernelGGL((fps_reg_kernel<1024, 4>), dim3(B), dim3(1024), lds, s, xyz, N, m, idx);
