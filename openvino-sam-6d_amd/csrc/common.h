@@ -57,16 +57,6 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 // ---- DPP / permlane reductions (no LDS crossbar: ds_bpermute costs an LDS round trip per step, these are plain VALU).
 // The summation ORDER differs from the xor butterfly above, so results can differ in the last bit: use them where no bit
 // recipe of the reference is pinned (attention, LayerNorm, focus, norms); max / min are order-independent.
@@ -111,6 +101,32 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
   v = fmaxf(v, xor16_f32(v));
   v = fmaxf(v, xor32_f32(v));
   return v;
+}
+
+__device__ __forceinline__ float row16_min_dpp(float v) {
+  v = fminf(v, dpp_f32<0x128>(v));
+  v = fminf(v, dpp_f32<0x124>(v));
+  v = fminf(v, dpp_f32<0x122>(v));
+  v = fminf(v, dpp_f32<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_min_dpp(float v) {
+  v = row16_min_dpp(v);
+  v = fminf(v, xor16_f32(v));
+  v = fminf(v, xor32_f32(v));
+  return v;
+}
+// max / min do not depend on the order of the reduction: the DPP form everywhere (round 4; the ds_bpermute butterfly cost six LDS round
+// trips per call in the latency-bound per-proposal kernels)
+__device__ __forceinline__ float wave_max(float v) { return wave_max_dpp(v); }
+__device__ __forceinline__ float wave_min(float v) { return wave_min_dpp(v); }
+// first maximum of (value, index) pairs over the wave: the largest value and, among the lanes that hold it, the lowest index (what a
+// sequential `v > best` scan in index order keeps).  Indices below 2^24 (exact as floats); index 0x7fffffff = "no element seen".
+__device__ __forceinline__ void wave_argmax_first(float& best, int& bi) {
+  const float m = wave_max_dpp(best);
+  const float nk = wave_max_dpp((best == m && bi != 0x7fffffff) ? -(float)bi : -3.0e38f);
+  best = m;
+  bi = nk < -1.0e30f ? 0x7fffffff : (int)(-nk);
 }
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {

@@ -271,6 +271,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk;
   const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
 
+  // (Measured and removed, round 4: a register ring of three k-steps -- the loads of step i + 2 issued while step i is multiplied -- on
+  // the theory that a K = 256 tile waits for eight HBM round trips: 256 VGPRs + 48 B of scratch, same bits, 65.9 / 75.7 us against
+  // 57.8 / 67.5 us for the 65536 x 256 x 256 in_proj / mlp3 launches (scratch/ub_gemm.py).  Two workgroups per CU already cover the
+  // latency of one step in flight; the kernel's 2.0-2.3 TB/s at K = 256 is staging work (split + LDS writes + range tracking) per byte.)
   float4 va[RA], vb[RB];
   half4 wbh[RB], wbl[RB];
   const bool wvec = WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0);

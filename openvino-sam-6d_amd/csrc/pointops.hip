@@ -579,6 +579,17 @@ extern "C" int sam6d_ball_query2(const float* new_xyz, const float* xyz, int B, 
 #define BQG_QPW 4            // queries per wave
 __host__ __device__ inline size_t bqg_cloud_bytes(int N) { return (size_t)N * 16 + (size_t)(BQG_CELLS + 1) * 4 + 12 + 16; }
 
+// inclusive prefix sum over the 64 lanes on the DPP path (no ds_bpermute round trips): Hillis-Steele inside each 16-lane row (row_shr
+// 1, 2, 4, 8 with zero fill), then the row totals of the rows before (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_scan_i32_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+  return v;
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -700,20 +711,16 @@ __global__ __launch_bounds__(256) void bqg_query_kernel(const float* __restrict_
       int cnt = 0;
 #pragma unroll
       for (int j = 0; j < WPL; ++j) { w[j] = m[lane * WPL + j]; cnt += __popc(w[j]); }
-      int inc = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int nb = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += nb;
-      }
-      const int total = __shfl(inc, 63, 64);
+      const int inc = wave_incl_scan_i32_dpp(cnt);
+      const int total = __builtin_amdgcn_readlane(inc, 63);
       int pos = inc - cnt;
-      // the first hit: lowest set bit of the first non-empty lane
-      int mine = 0x7fffffff;
+      // the first hit: lowest set bit of the first non-empty lane (lane order = index order)
+      int mine = 0;
 #pragma unroll
       for (int j = WPL - 1; j >= 0; --j)
         if (w[j]) mine = 32 * (lane * WPL + j) + (__ffs(w[j]) - 1);
-      const int first = total ? wave_min_i32(mine) : 0;
+      const unsigned long long any = __ballot(cnt > 0);
+      const int first = any ? __builtin_amdgcn_readlane(mine, __ffsll((long long)any) - 1) : 0;
 #pragma unroll
       for (int j = 0; j < WPL; ++j) {
         unsigned x = w[j];

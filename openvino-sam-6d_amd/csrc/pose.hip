@@ -139,15 +139,7 @@ __global__ __launch_bounds__(256) void sa_row_labels_kernel(const float* __restr
       bi = c;
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) {
-      best = ov;
-      bi = oi;
-    }
-  }
+  wave_argmax_first(best, bi);
   if (lane == 0) label1[w] = (bi == 0x7fffffff) ? 0 : bi;
 }
 
@@ -333,15 +325,7 @@ __global__ __launch_bounds__(1024) void coarse_assign_kernel(const float* __rest
         bi = c;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
+    wave_argmax_first(best, bi);
     if (lane == 0) l1[r] = (bi == 0x7fffffff) ? 0 : bi;
   }
   // ---- column labels: first maximum over the rows (a wave per column; ties -> the lower row, as the sequential scan keeps)
@@ -355,15 +339,7 @@ __global__ __launch_bounds__(1024) void coarse_assign_kernel(const float* __rest
         bi = r;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
+    wave_argmax_first(best, bi);
     if (lane == 0) l2[c] = (bi == 0x7fffffff) ? 0 : bi;
   }
   __syncthreads();
@@ -425,12 +401,28 @@ extern "C" int sam6d_coarse_soft_assign(const float* att, int B, int R, int C, f
 // inclusive wave scan in double per step plus the carried sum.  Pass 1 yields the 16 segment totals, pass 2 repeats the same
 // arithmetic with the segment's offset as the initial carry, rounds to float, divides by the row total and stores.
 // (The previous form gave each thread a contiguous chunk: strided loads and a 1024-wide LDS scan with 20 barriers, 116 us.)
+// (round 4: on the DPP path -- Hillis-Steele inside each 16-lane row with zero fill, then the totals of the rows before by row_bcast:15 /
+// row_bcast:31 -- instead of six ds_bpermute steps of two registers each; the sums are the same up to the association of the double
+// additions, 2^-29 below the float rounding the result goes through)
+template <int CTRL, int ROWS, bool ZERO>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, CTRL, ROWS, 0xf, ZERO);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), CTRL, ROWS, 0xf, ZERO);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double bcast63_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_incl_scan_f64(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double up = __shfl_up(v, o, 64);
-    if (lane >= o) v += up;
-  }
+  v += dpp_f64<0x111, 0xf, true>(v);   // row_shr:1
+  v += dpp_f64<0x112, 0xf, true>(v);   // row_shr:2
+  v += dpp_f64<0x114, 0xf, true>(v);   // row_shr:4
+  v += dpp_f64<0x118, 0xf, true>(v);   // row_shr:8
+  v += dpp_f64<0x142, 0xa, false>(v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_f64<0x143, 0xc, false>(v);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -445,7 +437,7 @@ __global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restri
   for (int k = 0; k < steps; ++k) {
     const int i = i0 + k * 64 + lane;
     const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
-    carry += __shfl(inc, 63, 64);
+    carry += bcast63_f64(inc);
   }
   if (lane == 0) s_tot[wave] = carry;
   __syncthreads();
@@ -462,7 +454,7 @@ __global__ __launch_bounds__(1024) void cumsum_norm_kernel(const float* __restri
     const int i = i0 + k * 64 + lane;
     const double inc = wave_incl_scan_f64((i < L) ? (double)x[i] : 0.0, lane);
     if (i < L) o[i] = (float)(carry + inc) / den;
-    carry += __shfl(inc, 63, 64);
+    carry += bcast63_f64(inc);
   }
 }
 
@@ -1025,12 +1017,7 @@ __global__ __launch_bounds__(64) void pick_best_kernel(const float* __restrict__
     const float v = scores[(size_t)b * k + i];
     if (v > best) { best = v; bi = i; }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-  }
+  wave_argmax_first(best, bi);
   if (bi == 0x7fffffff) bi = 0;
   const int h = sel[(size_t)b * k + bi];
   if (lane < 9) R[b * 9 + lane] = Rs[((size_t)b * nh + h) * 9 + lane];
