@@ -271,11 +271,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk;
   const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
 
-  // (Measured and removed, round 4: a register ring of three k-steps -- the loads of step i + 2 issued while step i is multiplied -- on
-  // the theory that a K = 256 tile waits for eight HBM round trips: 256 VGPRs + 48 B of scratch, same bits, 65.9 / 75.7 us against
-  // 57.8 / 67.5 us for the 65536 x 256 x 256 in_proj / mlp3 launches (scratch/ub_gemm.py).  Two workgroups per CU already cover the
-  // latency of one step in flight; the kernel's 2.0-2.3 TB/s at K = 256 is staging work (split + LDS writes + range tracking) per byte.)
-  float4 va[RA], vb[RB];
+  // Register ring of NS k-steps for the A rows (round 4): the loads of step i + NS - 1 are issued while step i is multiplied.  A is the
+  // HBM stream (each row is read once); the weight tile comes from L2 (every workgroup re-reads it) and keeps its single step in flight.
+  // Measured on the 65536 x 256 x 256 projections of the fine stage (scratch/ub_gemm.py, same bits): in_proj 57.3 -> 54.8 us, mlp3
+  // (+ residual) 66.5 -> 61.6 us.  (A ring over BOTH operands needed 256 VGPRs + 48 B of scratch and was slower: 65.9 / 75.7 us.)
+  // The kernel is not latency-bound at K = 256 as first assumed: rocprof counts ~3700 vector instructions per wave and tile (40 % of the
+  // SIMDs' issue cycles) against 128 MFMAs (16 %) -- staging, splitting and the epilogue per byte moved.
+  constexpr int NS = 3;
+  float4 va[NS][RA], vb[RB];
   half4 wbh[RB], wbl[RB];
   const bool wvec = WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0);
   auto fetch_w16 = [&](int k0) {  // pre-split weight rows: 8-byte loads of 4 halves
@@ -295,98 +298,112 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
       }
     }
   };
-  auto fetch = [&](int k0) {
-    if (WS) fetch_w16(k0);
+  auto fetch_a = [&](float4 (&fa)[RA], int k0) {
     if (vec && k0 + H_BK <= K) {
 #pragma unroll
-      for (int u = 0; u < RA; ++u) va[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
-      if (!WS) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
-      }
+      for (int u = 0; u < RA; ++u) fa[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
     } else {
       float tmp[4];
 #pragma unroll
       for (int u = 0; u < RA; ++u) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? ap[u][k0 + e] : 0.f;
-        va[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+        fa[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
       }
-      if (!WS) {
+    }
+  };
+  auto fetch_w = [&](int k0) {
+    if (WS) {
+      fetch_w16(k0);
+    } else if (vec && k0 + H_BK <= K) {
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
+      for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
+    } else {
+      float tmp[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
-          vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-        }
+      for (int u = 0; u < RB; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmp[e] = (k0 + sk + e) < K ? bp[u][k0 + e] : 0.f;
+        vb[u] = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
       }
     }
   };
 
   const int fr = lane & 31, fk = lane >> 5;
   float ma = 0.f, mw = 0.f;  // running max |A|, max |W| of what this thread stages (range check below)
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += H_BK) {
-    __syncthreads();
+  fetch_w(0);
 #pragma unroll
-    for (int u = 0; u < RA; ++u) {
-      ma = fmaxf(fmaxf(ma, fabsf(va[u].x)), fmaxf(fabsf(va[u].y), fmaxf(fabsf(va[u].z), fabsf(va[u].w))));
-      half4 hi, lo;
-      split4(va[u], hi, lo);
-      *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
-      if (!half) *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
-    }
+  for (int st = 0; st < NS - 1; ++st)
+    if (st * H_BK < K) fetch_a(va[st], st * H_BK);
+  for (int kb = 0; kb < K; kb += NS * H_BK) {
 #pragma unroll
-    for (int u = 0; u < RB; ++u) {
-      half4 hi, lo;
-      if (WS) {
-        hi = wbh[u];
-        lo = wbl[u];
-      } else {
-        mw = fmaxf(fmaxf(mw, fabsf(vb[u].x)), fmaxf(fabsf(vb[u].y), fmaxf(fabsf(vb[u].z), fabsf(vb[u].w))));
-        split4(vb[u], hi, lo);
-      }
-      *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
-      if (!half) *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
-    }
-    __syncthreads();
-    if (k0 + H_BK < K) fetch(k0 + H_BK);
-    if (half) {  // single product: hi halves only (workgroup-uniform branch)
+    for (int st = 0; st < NS; ++st) {
+      const int k0 = kb + st * H_BK;
+      if (k0 < K) {  // (uniform)
+        __syncthreads();
 #pragma unroll
-      for (int ks = 0; ks < H_BK; ks += 16) {
-        half8 ah[TM], bh[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      }
-      continue;
-    }
-#pragma unroll
-    for (int ks = 0; ks < H_BK; ks += 16) {
-      half8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
-        al[i] = *reinterpret_cast<const half8*>(&Al[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
-        bl[j] = *reinterpret_cast<const half8*>(&Bl[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int u = 0; u < RA; ++u) {
+          const float4 v = va[st][u];
+          ma = fmaxf(fmaxf(ma, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+          half4 hi, lo;
+          split4(v, hi, lo);
+          *reinterpret_cast<half4*>(&Ah[(sr + 32 * u) * H_LD + sk]) = hi;
+          if (!half) *reinterpret_cast<half4*>(&Al[(sr + 32 * u) * H_LD + sk]) = lo;
         }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          half4 hi, lo;
+          if (WS) {
+            hi = wbh[u];
+            lo = wbl[u];
+          } else {
+            mw = fmaxf(fmaxf(mw, fabsf(vb[u].x)), fmaxf(fabsf(vb[u].y), fmaxf(fabsf(vb[u].z), fabsf(vb[u].w))));
+            split4(vb[u], hi, lo);
+          }
+          *reinterpret_cast<half4*>(&Bh[(sr + 32 * u) * H_LD + sk]) = hi;
+          if (!half) *reinterpret_cast<half4*>(&Bl[(sr + 32 * u) * H_LD + sk]) = lo;
+        }
+        __syncthreads();
+        if (k0 + H_BK < K) fetch_w(k0 + H_BK);
+        if (k0 + (NS - 1) * H_BK < K) fetch_a(va[(st + NS - 1) % NS], k0 + (NS - 1) * H_BK);
+        if (half) {  // single product: hi halves only (workgroup-uniform branch)
+#pragma unroll
+          for (int ks = 0; ks < H_BK; ks += 16) {
+            half8 ah[TM], bh[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < H_BK; ks += 16) {
+            half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              ah[i] = *reinterpret_cast<const half8*>(&Ah[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+              al[i] = *reinterpret_cast<const half8*>(&Al[(wm + 32 * i + fr) * H_LD + ks + 8 * fk]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              bh[j] = *reinterpret_cast<const half8*>(&Bh[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+              bl[j] = *reinterpret_cast<const half8*>(&Bl[(wn + 32 * j + fr) * H_LD + ks + 8 * fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              }
+          }
+        }
+      }
     }
   }
   // ---- range of the fp16 split.  x = hi + lo carries 22 significand bits only while hi cannot overflow (|x| < 65520) and lo is not
