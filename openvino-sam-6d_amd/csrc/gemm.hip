@@ -224,12 +224,14 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // WS: the weight operand arrives pre-split -- Wh / Wl = fp16 hi / lo of W * 2^e, same (N, K) layout and strides as W, cut once at
 // weight-load time (sam6d_split_f16) -- so staging it is a copy: the per-k-step VALU split of the weight tile (half of the
 // kernel's vector work at K = 256) disappears, and so does its range check (the pack scale puts max |W| into [2^13, 2^14)).
-template <int BM, int BN, bool WS>
+// FAST: whole tiles (M % BM == 0 per batch entry, N % BN == 0, K % 32 == 0), 16-byte aligned operands, three products, the wide
+// epilogue without divisor / column scale / activation -- every guard of the general form is then a compile-time constant.
+template <int BM, int BN, bool WS, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
-                                                         long sC, long sR, float divisor, int act, Batch2 b2, int wide, int half,
+                                                         long sC, long sR, float divisor_, int act_, Batch2 b2, int wide_, int half_,
                                                          const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
                                                          float w_unscale) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -240,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   _Float16* Bh = Al + BM * H_LD;
   _Float16* Bl = Bh + BN * H_LD;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wide = FAST ? 1 : wide_, half = FAST ? 0 : half_, act = FAST ? 0 : act_;
+  const float divisor = FAST ? 1.0f : divisor_;
+  if (FAST) colscale = nullptr;
   int zz, tm_, tn_;
   if (!gemm_tile<BM, BN>(M, N, b2, zz, tm_, tn_)) return;  // padding workgroup (uniform)
   const int bz = zz / b2.n2, bi = zz % b2.n2;
@@ -266,10 +271,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   const float* ap[RA];
   const float* bp[RB];
 #pragma unroll
-  for (int u = 0; u < RA; ++u) ap[u] = A + (size_t)min(m0 + sr + 32 * u, M - 1) * lda + sk;
+  for (int u = 0; u < RA; ++u) ap[u] = A + (size_t)(FAST ? m0 + sr + 32 * u : min(m0 + sr + 32 * u, M - 1)) * lda + sk;
 #pragma unroll
-  for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk;
-  const bool vec = ((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0);
+  for (int u = 0; u < RB; ++u) bp[u] = W + (size_t)(FAST ? n0 + sr + 32 * u : min(n0 + sr + 32 * u, N - 1)) * ldw + sk;
+  const bool vec = FAST || (((lda & 3) == 0) && ((ldw & 3) == 0) && ((((size_t)A | (size_t)W) & 15) == 0));
 
   // Register ring of NS k-steps for the A rows (round 4): the loads of step i + NS - 1 are issued while step i is multiplied.  A is the
   // HBM stream (each row is read once); the weight tile comes from L2 (every workgroup re-reads it) and keeps its single step in flight.
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   constexpr int NS = 3;
   float4 va[NS][RA], vb[RB];
   half4 wbh[RB], wbl[RB];
-  const bool wvec = WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0);
+  const bool wvec = FAST || (WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0));
   auto fetch_w16 = [&](int k0) {  // pre-split weight rows: 8-byte loads of 4 halves
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
-      const size_t o = (size_t)min(n0 + sr + 32 * u, N - 1) * ldw + sk + k0;
-      if (wvec && k0 + H_BK <= K) {
+      const size_t o = (size_t)(FAST ? n0 + sr + 32 * u : min(n0 + sr + 32 * u, N - 1)) * ldw + sk + k0;
+      if (wvec && (FAST || k0 + H_BK <= K)) {
         wbh[u] = *reinterpret_cast<const half4*>(Wh + o);
         wbl[u] = *reinterpret_cast<const half4*>(Wl + o);
       } else {
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
     }
   };
   auto fetch_a = [&](float4 (&fa)[RA], int k0) {
-    if (vec && k0 + H_BK <= K) {
+    if (vec && (FAST || k0 + H_BK <= K)) {
 #pragma unroll
       for (int u = 0; u < RA; ++u) fa[u] = *reinterpret_cast<const float4*>(ap[u] + k0);
     } else {
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   auto fetch_w = [&](int k0) {
     if (WS) {
       fetch_w16(k0);
-    } else if (vec && k0 + H_BK <= K) {
+    } else if (vec && (FAST || k0 + H_BK <= K)) {
 #pragma unroll
       for (int u = 0; u < RB; ++u) vb[u] = *reinterpret_cast<const float4*>(bp[u] + k0);
     } else {
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
     for (int jp = 0; jp < TN / EJ; ++jp) {
       const int col = n0 + wn + jp * WC + c4;
       float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f), cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (col < N) {
+      if (FAST || col < N) {
         if (bias) bv4 = *reinterpret_cast<const float4*>(bias + col);
         if (colscale) cs4 = *reinterpret_cast<const float4*>(colscale + col);
       }
@@ -462,14 +467,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         const int row = m0 + wm + i * 32 + it * RPP + rr0;
-        rv[it] = (residual && row < M && col < N) ? *reinterpret_cast<const float4*>(residual + (size_t)row * ldr + col)
+        rv[it] = (residual && (FAST || (row < M && col < N))) ? *reinterpret_cast<const float4*>(residual + (size_t)row * ldr + col)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         const int rr = it * RPP + rr0;
         const int row = m0 + wm + i * 32 + rr;
-        if (row < M && col < N) {
+        if (FAST || (row < M && col < N)) {
           float4 v = *reinterpret_cast<const float4*>(&slab[rr * SLD + c4]);
           float e[4] = {v.x, v.y, v.z, v.w};
           const float bb[4] = {bv4.x, bv4.y, bv4.z, bv4.w}, cc[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
@@ -539,6 +544,15 @@ extern "C" int sam6d_set_thread_matmul_mode(int mode) {
 extern "C" int sam6d_get_matmul_mode(void) { return t_matmul_mode >= 0 ? t_matmul_mode : g_matmul_mode; }
 extern "C" int sam6d_get_thread_matmul_mode(void) { return t_matmul_mode; }
 
+static bool gemm_fast_enabled() {  // SAM6D_GEMM_FAST=0: the general kernel also for whole-tile launches (A/B runs)
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SAM6D_GEMM_FAST");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on != 0;
+}
+
 static int gemm_launch(const float* A, const float* W, const float* bias, const float* colscale, const float* residual,
                        float* C, int M, int N, int K, long lda, long ldw, long ldc, long ldr, int batch, long sA, long sW,
                        long sC, long sR, Batch2 b2, float divisor, int act, void* stream, const void* Wh = nullptr,
@@ -581,7 +595,11 @@ static int gemm_launch(const float* A, const float* W, const float* bias, const 
     const _Float16* wl = reinterpret_cast<const _Float16*>(Wl);
     const float wu = 1.0f / w_scale;
     if (wh && wl) {
-      if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, true>), wide, half, wh, wl, wu);
+      const bool fast = big && wide && !half && (M % 128) == 0 && (N % 128) == 0 && (K % 32) == 0 && (lda & 3) == 0 && (ldw & 3) == 0 &&
+                        ((((size_t)A | (size_t)W) & 15) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0) && (sA & 3) == 0 && (b2.sA2 & 3) == 0 &&
+                        (sW & 3) == 0 && (b2.sW2 & 3) == 0 && divisor == 1.0f && !colscale && act == 0 && gemm_fast_enabled();
+      if (fast) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, true, true>), wide, half, wh, wl, wu);
+      else if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, true>), wide, half, wh, wl, wu);
       else GEMM_LAUNCH((gemm_nt_h3_kernel<64, 64, true>), wide, half, wh, wl, wu);
     } else {
       if (big) GEMM_LAUNCH((gemm_nt_h3_kernel<128, 128, false>), wide, half, wh, wl, wu);
