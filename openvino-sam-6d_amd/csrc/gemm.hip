@@ -227,7 +227,7 @@ __device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
 // FAST: whole tiles (M % BM == 0 per batch entry, N % BN == 0, K % 32 == 0), 16-byte aligned operands, three products, the wide
 // epilogue without divisor / column scale / activation -- every guard of the general form is then a compile-time constant.
 template <int BM, int BN, bool WS, bool FAST = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, FAST ? 3 : 2) void gemm_nt_h3_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const float* __restrict__ colscale,
                                                          const float* __restrict__ residual, float* __restrict__ C, int M,
                                                          int N, int K, long lda, long ldw, long ldc, long ldr, long sA, long sW,
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_h3_kernel(const float* __restr
   // (+ residual) 66.5 -> 61.6 us.  (A ring over BOTH operands needed 256 VGPRs + 48 B of scratch and was slower: 65.9 / 75.7 us.)
   // The kernel is not latency-bound at K = 256 as first assumed: rocprof counts ~3700 vector instructions per wave and tile (40 % of the
   // SIMDs' issue cycles) against 128 MFMAs (16 %) -- staging, splitting and the epilogue per byte moved.
-  constexpr int NS = 3;
+  constexpr int NS = FAST ? 2 : 3;  // (FAST runs three workgroups per CU: 168 registers)
   float4 va[NS][RA], vb[RB];
   half4 wbh[RB], wbl[RB];
   const bool wvec = FAST || (WS && ((ldw & 3) == 0) && ((((size_t)Wh | (size_t)Wl) & 7) == 0));
