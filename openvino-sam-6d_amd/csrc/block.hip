@@ -158,84 +158,106 @@ __device__ __forceinline__ float tbk_softplus(float x) { return x > 20.0f ? x : 
 // threads own kv^T[h][d][c0 .. c0 + 15] of their head, the four waves stage the 16 key rows of a step (a wave = one 256-channel row:
 // the focus norms need the whole row, only the head's 64 k and 64 v channels go to LDS), every head gets its own power-of-two scale.
 // Same phi(k), same per-output accumulation order: kv^T and the key sums keep their bits.
-__global__ __launch_bounds__(256) void tb_kv_fused_kernel(const float* __restrict__ kv, const float* __restrict__ scale, int J, long ld,
-                                                          long sb, unsigned char* __restrict__ image, float* __restrict__ inv,
-                                                          float* __restrict__ ksum) {
-  __shared__ float ks[16][64];
-  __shared__ float vs[16][68];
-  __shared__ float red[4];
+// Round 4: THREADS per (cloud, head) workgroup is a template parameter.  With 256 threads (round 3) a CU held four waves, one per SIMD,
+// and a step's chain -- four rows of phi(k) per wave with two wave reductions each, then 16 keys x (LDS reads + 16 fma) per thread --
+// ran without anything to overlap with: 56 us, unchanged by deeper row prefetch (58.7 us with a four-step register ring: not a load-
+// latency problem).  1024 threads: one row per wave and step, four outputs per thread, sixteen waves per CU.  The accumulation order
+// of every output (keys ascending) does not depend on the thread that owns it: same bits.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void tb_kv_fused_kernel(const float* __restrict__ kv, const float* __restrict__ scale, int J, long ld,
+                                                              long sb, unsigned char* __restrict__ image, float* __restrict__ inv,
+                                                              float* __restrict__ ksum) {
+  constexpr int NW = THREADS / 64, RPW = 16 / NW;   // waves, key rows per wave and step
+  constexpr int OPT = 4096 / THREADS, TPR = 64 / OPT;  // outputs per thread, threads per kv^T row
+  __shared__ __attribute__((aligned(16))) float ks[16][64];
+  __shared__ __attribute__((aligned(16))) float vs[16][68];
+  __shared__ float red[NW];
   const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* kb = kv + (size_t)b * sb;
   const float4 sc = *reinterpret_cast<const float4*>(scale + lane * 4);
   const float sp[4] = {tbk_softplus(sc.x), tbk_softplus(sc.y), tbk_softplus(sc.z), tbk_softplus(sc.w)};
-  const int d = t >> 2, c0 = (t & 3) * 16;
+  const int d = t / TPR, c0 = (t % TPR) * OPT;
   const bool mine = (lane >> 4) == h;  // this lane's 4 channels belong to head h
-  float acc[16];
+  float acc[OPT];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+  for (int u = 0; u < OPT; ++u) acc[u] = 0.f;
   float ksacc = 0.f;  // threads t < 64 accumulate ksum[h][c = t]
-  // this wave's four key rows of a step (rows wave, wave + 4, ...): all eight loads in flight at once, and the NEXT step's rows are
-  // requested before this step's accumulation (the loop was a chain of load round trips: 63 us for 13 steps)
-  float4 xr[4], vr[4];
-  auto fetch = [&](int j0) {
+  // this wave's key rows of a step (rows wave, wave + NW, ...) in a register ring of NS steps: the rows of step i + NS - 1 are requested
+  // before step i is accumulated.  (NS = 4 measured: 58.7 against 56.4 us at 256 threads, 41.1 against 41.3 us at 1024 -- the loop is
+  // bound by the instructions it issues, ~130 per key row for phi(k) with its eight IEEE divisions and ~130 per step and wave for the
+  // accumulation, not by the loads.)
+  constexpr int NS = 2;
+  float4 xr[NS][RPW], vr[NS][RPW];
+  auto fetch = [&](float4 (&xq)[RPW], float4 (&vq)[RPW], int j0) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = j0 + 4 * rr + wave;
-      xr[rr] = vr[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int j = j0 + NW * rr + wave;
+      xq[rr] = vq[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < J) {
-        xr[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + lane * 4);
-        vr[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + 256 + lane * 4);
+        xq[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + lane * 4);
+        vq[rr] = *reinterpret_cast<const float4*>(kb + (size_t)j * ld + 256 + lane * 4);
       }
     }
   };
-  fetch(0);
-  for (int j0 = 0; j0 < J; j0 += 16) {
-    __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int jr = 4 * rr + wave, j = j0 + jr;
-      float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 vx = vr[rr];
-      if (j < J) {
-        const float4 x = xr[rr];
-        float a[4] = {x.x, x.y, x.z, x.w}, c[4];
-        float n1 = 0.f, n3 = 0.f;
+  for (int st = 0; st < NS - 1; ++st)
+    if (st * 16 < J) fetch(xr[st], vr[st], st * 16);
+  for (int jb = 0; jb < J; jb += NS * 16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float v = (a[u] > 0.f ? a[u] : 0.f) + 1e-6f;
-          v = v / sp[u];
-          n1 += v * v;
-          c[u] = (v * v) * v;
-          n3 += c[u] * c[u];
+    for (int st = 0; st < NS; ++st) {
+      const int j0 = jb + st * 16;
+      if (j0 < J) {  // (uniform)
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int jr = NW * rr + wave, j = j0 + jr;
+          float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 vx = vr[st][rr];
+          if (j < J) {
+            const float4 x = xr[st][rr];
+            float a[4] = {x.x, x.y, x.z, x.w}, c[4];
+            float n1 = 0.f, n3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float v = (a[u] > 0.f ? a[u] : 0.f) + 1e-6f;
+              v = v / sp[u];
+              n1 += v * v;
+              c[u] = (v * v) * v;
+              n3 += c[u] * c[u];
+            }
+            n1 = sqrtf(wave_sum_dpp(n1));
+            n3 = sqrtf(wave_sum_dpp(n3));
+            kx = make_float4((c[0] / n3) * n1, (c[1] / n3) * n1, (c[2] / n3) * n1, (c[3] / n3) * n1);
+          }
+          if (mine) {
+            *reinterpret_cast<float4*>(&ks[jr][(lane & 15) * 4]) = kx;
+            *reinterpret_cast<float4*>(&vs[jr][(lane & 15) * 4]) = vx;
+          }
         }
-        n1 = sqrtf(wave_sum_dpp(n1));
-        n3 = sqrtf(wave_sum_dpp(n3));
-        kx = make_float4((c[0] / n3) * n1, (c[1] / n3) * n1, (c[2] / n3) * n1, (c[3] / n3) * n1);
-      }
-      if (mine) {
-        *reinterpret_cast<float4*>(&ks[jr][(lane & 15) * 4]) = kx;
-        *reinterpret_cast<float4*>(&vs[jr][(lane & 15) * 4]) = vx;
-      }
-    }
-    __syncthreads();
-    if (j0 + 16 < J) fetch(j0 + 16);
+        __syncthreads();
+        if (j0 + (NS - 1) * 16 < J) fetch(xr[(st + NS - 1) % NS], vr[(st + NS - 1) % NS], j0 + (NS - 1) * 16);
 #pragma unroll 4
-    for (int jj = 0; jj < 16; ++jj) {
-      const float vv = vs[jj][d];
+        for (int jj = 0; jj < 16; ++jj) {
+          const float vv = vs[jj][d];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] = fmaf(ks[jj][c0 + u], vv, acc[u]);
-      if (t < 64) ksacc += ks[jj][t];
+          for (int u = 0; u < OPT; ++u) acc[u] = fmaf(ks[jj][c0 + u], vv, acc[u]);
+          if (t < 64) ksacc += ks[jj][t];
+        }
+      }
     }
   }
   if (t < 64) ksum[((size_t)b * 4 + h) * 64 + t] = ksacc;
   // the head's scale from max |kv^T_h|
   float m = 0.f;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) m = fmaxf(m, fabsf(acc[u]));
+  for (int u = 0; u < OPT; ++u) m = fmaxf(m, fabsf(acc[u]));
   m = wave_max_dpp(m);
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  const float s2 = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  float mm = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mm = fmaxf(mm, red[w]);
+  const float s2 = pow2_scale_for(mm);
   if (t == 0) inv[(size_t)b * 4 + h] = 1.0f / s2;
   // image: head h, row d -> panel 2 h + (d >> 5), row m = d & 31; channel c sits in slot p = 32 (c >> 5) + 8 g + e of the 64-wide K
   // (tb_slot_channel inverted: g = (c >> 2) & 3, e = 4 ((c >> 4) & 1) + (c & 3))
@@ -243,7 +265,7 @@ __global__ __launch_bounds__(256) void tb_kv_fused_kernel(const float* __restric
   _Float16* row = reinterpret_cast<_Float16*>(image + (size_t)b * (8 * TB_P64) + (size_t)(2 * h + (d >> 5)) * TB_P64 +
                                               (size_t)mrow * TB_ROWB(2));
 #pragma unroll
-  for (int u = 0; u < 16; u += 2) {
+  for (int u = 0; u < OPT; u += 2) {
     unsigned hi, lo;
     sam6d_split2_f16(acc[u] * s2, acc[u + 1] * s2, hi, lo);
     const _Float16 __attribute__((ext_vector_type(2))) h2 = __builtin_bit_cast(_Float16 __attribute__((ext_vector_type(2))), hi);
@@ -264,8 +286,20 @@ extern "C" int sam6d_linattn_kv_image(const float* kv, const float* scale, int B
                     (((size_t)kv | (size_t)scale) & 15) == 0,
                 "linattn_kv_image: bad arguments (kv rows = 256 k | 256 v channels, 16-byte aligned)");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(tb_kv_fused_kernel, dim3(4, B), dim3(256), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
-                     (unsigned char*)image, inv, ksum);
+  static int shape = -1;  // SAM6D_KV_THREADS = 256 / 512 / 1024 (A/B runs)
+  if (shape < 0) {
+    const char* e = getenv("SAM6D_KV_THREADS");
+    shape = e ? atoi(e) : 1024;
+  }
+  if (shape == 256)
+    hipLaunchKernelGGL(tb_kv_fused_kernel<256>, dim3(4, B), dim3(256), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
+                       (unsigned char*)image, inv, ksum);
+  else if (shape == 512)
+    hipLaunchKernelGGL(tb_kv_fused_kernel<512>, dim3(4, B), dim3(512), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
+                       (unsigned char*)image, inv, ksum);
+  else
+    hipLaunchKernelGGL(tb_kv_fused_kernel<1024>, dim3(4, B), dim3(1024), 0, (hipStream_t)stream, kv, scale, J, ld, stride,
+                       (unsigned char*)image, inv, ksum);
   SAM6D_LAUNCH_CHECK("linattn_kv_image");
 }
 
