@@ -1244,55 +1244,119 @@ extern "C" int sam6d_fine_assign(const float* att, int B, int R, int C, const fl
 
 // N-point weighted Procrustes, one workgroup per batch element (model_utils.py:343-436):
 // w <- where(w < thresh, 0, w);  w <- w / (sum w + eps);  centroids;  H = sum (src - sc)^T (w (ref - rc));  R, t.
-__device__ __forceinline__ double block_sum_d(double v, double* red) {
-  v = wave_sum(v);
+// Round 4: the workgroup's points stay in registers across the three passes (weight sum -> centroids -> correlation matrix; 8 points per
+// thread at N = 2048), and the sums of a pass are reduced TOGETHER: a DPP prefix sum per value and wave (its last lane holds the wave
+// total), one LDS exchange and one barrier pair per pass instead of one ds_bpermute butterfly + barrier pair per value (16 of them:
+// 24 us for a few kiloflops).  Sums stay in double; only their association changes (1e-16 relative, far below the float results).
+template <int NV>
+__device__ __forceinline__ void block_sum_dv(double (&v)[NV], double (*red)[9]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_incl_scan_f64(v[k], lane);
+  __syncthreads();  // (the previous pass has read `red`)
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wave][k] = v[k];
+  }
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
 
+#define PR_PPT 8  // points per thread held in registers (N <= 256 * PR_PPT; longer clouds re-read)
 __global__ __launch_bounds__(256) void procrustes_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                          const float* __restrict__ wts, int N, float thresh, float eps,
                                                          float* __restrict__ Rout, float* __restrict__ tout) {
-  __shared__ double red[4];
+  __shared__ double red[4][9];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* S = src + (size_t)b * N * 3;
   const float* Q = ref + (size_t)b * N * 3;
   const float* W = wts ? wts + (size_t)b * N : nullptr;
-  double sw = 0.0;
-  for (int i = t; i < N; i += 256) {
-    float w = W ? W[i] : 1.0f;
-    if (w < thresh) w = 0.f;
-    sw += (double)w;
+  const bool cached = N <= 256 * PR_PPT;
+  float cw[PR_PPT], cs[PR_PPT][3], cq[PR_PPT][3];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PR_PPT; ++u) {
+      const int i = t + 256 * u;
+      const bool ok = i < N;
+      float w = (ok && W) ? W[i] : (ok ? 1.0f : 0.0f);
+      if (w < thresh) w = 0.f;
+      cw[u] = w;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        cs[u][d] = ok ? S[i * 3 + d] : 0.f;
+        cq[u][d] = ok ? Q[i * 3 + d] : 0.f;
+      }
+    }
   }
-  sw = block_sum_d(sw, red);
-  const float den = (float)sw + eps;
+  double sw[1] = {0.0};
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PR_PPT; ++u) sw[0] += (double)cw[u];
+  } else {
+    for (int i = t; i < N; i += 256) {
+      float w = W ? W[i] : 1.0f;
+      if (w < thresh) w = 0.f;
+      sw[0] += (double)w;
+    }
+  }
+  block_sum_dv<1>(sw, red);
+  const float den = (float)sw[0] + eps;
   double c[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = t; i < N; i += 256) {
-    float w = W ? W[i] : 1.0f;
-    if (w < thresh) w = 0.f;
-    const double wn = (double)(w / den);
-    for (int d = 0; d < 3; ++d) {
-      c[d] += (double)S[i * 3 + d] * wn;
-      c[3 + d] += (double)Q[i * 3 + d] * wn;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PR_PPT; ++u) {
+      const double wn = (double)(cw[u] / den);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        c[d] += (double)cs[u][d] * wn;
+        c[3 + d] += (double)cq[u][d] * wn;
+      }
+    }
+  } else {
+    for (int i = t; i < N; i += 256) {
+      float w = W ? W[i] : 1.0f;
+      if (w < thresh) w = 0.f;
+      const double wn = (double)(w / den);
+      for (int d = 0; d < 3; ++d) {
+        c[d] += (double)S[i * 3 + d] * wn;
+        c[3 + d] += (double)Q[i * 3 + d] * wn;
+      }
     }
   }
-  for (int d = 0; d < 6; ++d) c[d] = block_sum_d(c[d], red);
+  block_sum_dv<6>(c, red);
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = t; i < N; i += 256) {
-    float w = W ? W[i] : 1.0f;
-    if (w < thresh) w = 0.f;
-    const double wn = (double)(w / den);
-    double s[3], q[3];
-    for (int d = 0; d < 3; ++d) {
-      s[d] = (double)S[i * 3 + d] - c[d];
-      q[d] = wn * ((double)Q[i * 3 + d] - c[3 + d]);
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PR_PPT; ++u) {
+      const double wn = (double)(cw[u] / den);
+      double sd[3], qd[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        sd[d] = (double)cs[u][d] - c[d];
+        qd[d] = wn * ((double)cq[u][d] - c[3 + d]);
+      }
+      // (a padding slot has weight 0: its q terms are exact zeros)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) H[a * 3 + d] += sd[a] * qd[d];
     }
-    for (int a = 0; a < 3; ++a)
-      for (int d = 0; d < 3; ++d) H[a * 3 + d] += s[a] * q[d];
+  } else {
+    for (int i = t; i < N; i += 256) {
+      float w = W ? W[i] : 1.0f;
+      if (w < thresh) w = 0.f;
+      const double wn = (double)(w / den);
+      double sd[3], qd[3];
+      for (int d = 0; d < 3; ++d) {
+        sd[d] = (double)S[i * 3 + d] - c[d];
+        qd[d] = wn * ((double)Q[i * 3 + d] - c[3 + d]);
+      }
+      for (int a = 0; a < 3; ++a)
+        for (int d = 0; d < 3; ++d) H[a * 3 + d] += sd[a] * qd[d];
+    }
   }
-  for (int d = 0; d < 9; ++d) H[d] = block_sum_d(H[d], red);
+  block_sum_dv<9>(H, red);
   if (t == 0) {
     double R[9];
     rotation_from_H(H, R);
@@ -1311,13 +1375,15 @@ extern "C" int sam6d_weighted_procrustes(const float* src, const float* ref, con
 
 // Fine pose score (model_utils.py:331-339):  dis_i = min_m |(p1_i - t) R - model_m|;  mask = [label1 > 0];
 // score = sum([dis < thr] * mask) / (sum(mask) + 1e-8) * mean(mask);  t_out = t * (radius + 1e-6) (fine_point_matching.py:78)
+// Round 4: a workgroup owns 64 points and its four waves each scan a quarter of the CAD points (the minimum does not depend on the order;
+// was: 256 points per workgroup, every thread walking all P model points alone -- one wave per SIMD on a 1024-step chain, 31 us).
 __global__ __launch_bounds__(256) void fine_near_kernel(const float* __restrict__ pts1, const float* __restrict__ R,
                                                         const float* __restrict__ t, const float* __restrict__ model,
                                                         const float* __restrict__ radius, const int* __restrict__ label1, int N,
                                                         int P, float thr, float* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  __shared__ float red[2][4];
-  const int b = blockIdx.y, tid = threadIdx.x;
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float den = radius[b] + 1e-6f;
   const float* mb = model + (size_t)b * P * 3;
   for (int i = tid; i < P; i += 256) {
@@ -1325,8 +1391,8 @@ __global__ __launch_bounds__(256) void fine_near_kernel(const float* __restrict_
     sm[i * 4] = x; sm[i * 4 + 1] = y; sm[i * 4 + 2] = z; sm[i * 4 + 3] = sqnorm3(x, y, z);
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + tid;
-  float near = 0.f, mk = 0.f;
+  const int i = blockIdx.x * 64 + lane;
+  float mn = INFINITY;
   if (i < N) {
     const float* Rb = R + b * 9;
     const float* p = pts1 + ((size_t)b * N + i) * 3;
@@ -1335,19 +1401,112 @@ __global__ __launch_bounds__(256) void fine_near_kernel(const float* __restrict_
     const float x1 = fmaf(d2, Rb[7], fmaf(d1, Rb[4], d0 * Rb[1]));
     const float x2 = fmaf(d2, Rb[8], fmaf(d1, Rb[5], d0 * Rb[2]));
     const float sx = sqnorm3(x0, x1, x2);
-    float mn = INFINITY;
-    for (int m = 0; m < P; ++m) {
+    const int chunk = (P + 3) >> 2, m0 = wave * chunk, m1 = min(P, m0 + chunk);
+    for (int m = m0; m < m1; ++m) {
       const float4 q = *reinterpret_cast<const float4*>(&sm[m * 4]);
       mn = fminf(mn, pdist3(x0, x1, x2, sx, q.x, q.y, q.z, q.w));
     }
-    mk = label1[(size_t)b * N + i] > 0 ? 1.f : 0.f;
-    near = (sqrtf(mn) < thr) ? mk : 0.f;
   }
-  near = wave_sum(near);
-  mk = wave_sum(mk);
-  if ((tid & 63) == 0) { red[0][tid >> 6] = near; red[1][tid >> 6] = mk; }
+  part[wave][lane] = mn;
   __syncthreads();
-  if (tid == 0) {  // integer-valued partial sums: exact in fp32 whatever the arrival order
+  if (wave == 0) {
+    float near = 0.f, mk = 0.f;
+    if (i < N) {
+      mn = fminf(fminf(part[0][lane], part[1][lane]), fminf(part[2][lane], part[3][lane]));
+      mk = label1[(size_t)b * N + i] > 0 ? 1.f : 0.f;
+      near = (sqrtf(mn) < thr) ? mk : 0.f;
+    }
+    near = wave_sum_dpp(near);  // integer-valued partial sums: exact in fp32 whatever the order
+    mk = wave_sum_dpp(mk);
+    if (lane == 0) {
+      atomicAdd(&cnt[b * 2], near);
+      atomicAdd(&cnt[b * 2 + 1], mk);
+    }
+  }
+}
+
+// The same count on the fp32 matrix cores, in the arithmetic of score_hyp_mfma_kernel (two v_mfma_f32_32x32x2_f32 on a zero accumulator
+// give rn(|x|^2 - 2 xy) in the fma order of pdist3, the vector ALU adds |y|^2 and keeps the running minimum: the same bits as
+// fine_near_kernel, whose thread walks the P CAD points with ~8 vector instructions per pair -- 31 us for 32 x 2048 x 1024 pairs).
+// A wave owns FN_CT column tiles of 32 scene points and walks the 32-row tiles of the CAD points.
+#define FN_CT 2
+__global__ __launch_bounds__(256) void fine_near_mfma_kernel(const float* __restrict__ pts1, const float* __restrict__ R,
+                                                             const float* __restrict__ t, const float* __restrict__ model,
+                                                             const float* __restrict__ radius, const int* __restrict__ label1, int N,
+                                                             int P, int Ppad, float thr, float* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][Ppad]: -2 y0 | -2 y1 | -2 y2 | 1;  then [Ppad]: |y|^2 (+inf padding)
+  __shared__ float red[2][4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kk = lane >> 5;
+  const float den = radius[b] + 1e-6f;
+  const float* mb = model + (size_t)b * P * 3;
+  for (int i = tid; i < Ppad; i += 256) {
+    float x = 0.f, y = 0.f, z = 0.f, sq = INFINITY;
+    if (i < P) {
+      x = mb[i * 3] / den; y = mb[i * 3 + 1] / den; z = mb[i * 3 + 2] / den;
+      sq = sqnorm3(x, y, z);
+    }
+    sm[i] = -2.0f * x; sm[Ppad + i] = -2.0f * y; sm[2 * Ppad + i] = -2.0f * z; sm[3 * Ppad + i] = 1.0f;
+    sm[4 * Ppad + i] = sq;
+  }
+  const int e0 = (blockIdx.x * 4 + wave) * FN_CT * 32 + j;
+  const float* Rb = R + b * 9;
+  float b1[FN_CT], b2[FN_CT], mn[FN_CT];
+#pragma unroll
+  for (int c = 0; c < FN_CT; ++c) {
+    const int i = e0 + 32 * c;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, sx = 0.f;
+    if (i < N) {
+      const float* p = pts1 + ((size_t)b * N + i) * 3;
+      const float d0 = p[0] - t[b * 3], d1 = p[1] - t[b * 3 + 1], d2 = p[2] - t[b * 3 + 2];
+      x0 = fmaf(d2, Rb[6], fmaf(d1, Rb[3], d0 * Rb[0]));
+      x1 = fmaf(d2, Rb[7], fmaf(d1, Rb[4], d0 * Rb[1]));
+      x2 = fmaf(d2, Rb[8], fmaf(d1, Rb[5], d0 * Rb[2]));
+      sx = sqnorm3(x0, x1, x2);
+    }
+    b1[c] = kk ? x1 : x0;
+    b2[c] = kk ? sx : x2;
+    mn[c] = INFINITY;
+  }
+  __syncthreads();
+  f32x16 zero;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) zero[v] = 0.f;
+  const float* a1p = sm + kk * Ppad + j;
+  const float* a2p = sm + (2 + kk) * Ppad + j;
+  const float* syp = sm + 4 * Ppad + kk * 4;
+  for (int r = 0; r < Ppad; r += 32) {
+    const float a1 = a1p[r], a2 = a2p[r];
+    const float4 s0 = *reinterpret_cast<const float4*>(syp + r), s1 = *reinterpret_cast<const float4*>(syp + r + 8);
+    const float4 s2 = *reinterpret_cast<const float4*>(syp + r + 16), s3 = *reinterpret_cast<const float4*>(syp + r + 24);
+#pragma unroll
+    for (int c = 0; c < FN_CT; ++c) {
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[c], zero, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[c], acc, 0, 0, 0);
+      // accumulator register v of this lane: CAD row r + 8 (v >> 2) + 4 kk + (v & 3), column j
+      const float m0 = fminf(fminf(acc[0] + s0.x, acc[1] + s0.y), fminf(acc[2] + s0.z, acc[3] + s0.w));
+      const float m1 = fminf(fminf(acc[4] + s1.x, acc[5] + s1.y), fminf(acc[6] + s1.z, acc[7] + s1.w));
+      const float m2 = fminf(fminf(acc[8] + s2.x, acc[9] + s2.y), fminf(acc[10] + s2.z, acc[11] + s2.w));
+      const float m3 = fminf(fminf(acc[12] + s3.x, acc[13] + s3.y), fminf(acc[14] + s3.z, acc[15] + s3.w));
+      mn[c] = fminf(fminf(mn[c], m0), fminf(fminf(m1, m2), m3));
+    }
+  }
+  float near = 0.f, mk = 0.f;
+#pragma unroll
+  for (int c = 0; c < FN_CT; ++c) {
+    float m = fminf(mn[c], __shfl_xor(mn[c], 32, 64));
+    m = m < 0.0f ? 0.0f : m;  // pdist3's clamp (it commutes with the minimum)
+    const int i = e0 + 32 * c;
+    if (kk == 0 && i < N) {
+      const float k1 = label1[(size_t)b * N + i] > 0 ? 1.f : 0.f;
+      mk += k1;
+      near += (sqrtf(m) < thr) ? k1 : 0.f;
+    }
+  }
+  near = wave_sum_dpp(near);  // integer-valued partial sums: exact in fp32 whatever the order
+  mk = wave_sum_dpp(mk);
+  if (lane == 0) { red[0][wave] = near; red[1][wave] = mk; }
+  __syncthreads();
+  if (tid == 0) {
     atomicAdd(&cnt[b * 2], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
     atomicAdd(&cnt[b * 2 + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
   }
@@ -1374,9 +1533,25 @@ extern "C" int sam6d_fine_score(const float* pts1, const float* R, float* t, con
   SAM6D_REQUIRE(B >= 0 && N > 0 && P > 0 && P <= 8192 && B <= 65535, "fine_score: bad sizes (P <= 8192)");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  static unsigned long long fn_done = 0;
+  if (sam6d_first_use_on_device(&fn_done)) {  // P = 8192 CAD points are 128 KB of dynamic LDS (the default limit is 64 KB)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fine_near_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
+    if (e != hipSuccess) {
+      sam6d_set_error("fine_score: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    sam6d_setup_done_on_device(&fn_done);
+  }
   hipLaunchKernelGGL(zero_kernel, dim3(cdiv(2 * B, 256)), dim3(256), 0, s, cnt_ws, 2 * B);
-  hipLaunchKernelGGL(fine_near_kernel, dim3(cdiv(N, 256), B), dim3(256), (size_t)P * 16, s, pts1, R, t, model, radius, label1, N, P,
-                     dis_thres, cnt_ws);
+  const char* fn_env = getenv("SAM6D_FINE_NEAR_MFMA");  // A/B switch, read per call (one call per step): 0 = the vector-ALU kernel
+  const int use_mfma = (fn_env && fn_env[0] == '0') ? 0 : 1;
+  const int Ppad = (P + 31) & ~31;
+  if (use_mfma && (size_t)Ppad * 20 <= 65536 - 64)
+    hipLaunchKernelGGL(fine_near_mfma_kernel, dim3(cdiv(N, 4 * FN_CT * 32), B), dim3(256), (size_t)Ppad * 20, s, pts1, R, t, model, radius,
+                       label1, N, P, Ppad, dis_thres, cnt_ws);
+  else
+    hipLaunchKernelGGL(fine_near_kernel, dim3(cdiv(N, 64), B), dim3(256), (size_t)P * 16, s, pts1, R, t, model, radius, label1, N, P,
+                       dis_thres, cnt_ws);
   hipLaunchKernelGGL(fine_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, cnt_ws, radius, B, N, t, score);
   SAM6D_LAUNCH_CHECK("fine_score");
 }

@@ -512,6 +512,64 @@ def test_fine_rt_radius_rescale(dev):
     _close(R, oR, 1e-4, "R"); _close(t, ot, 1e-4, "t"); _close(s, os_, 1e-5, "score")
 
 
+@pytest.mark.parametrize("P", [500, 4096, 5000, 8192])
+def test_fine_score_large_model_cloud(dev, P):
+    """sam6d_fine_score (the nearest-CAD-point count of compute_fine_Rt, model_utils.py:331-339) with up to 8192 CAD points -- 128 KB of
+    dynamic LDS -- and a point count that is not a multiple of the 64-point workgroups: against a float64 recompute; points whose nearest
+    distance lies within 1e-6 of the threshold may fall on either side."""
+    from sam6d_hip import _lib
+    gen = torch.Generator().manual_seed(P)
+    B, N = 3, 301
+    p1 = (torch.rand(B, N, 3, generator=gen) - 0.5)
+    model = (torch.rand(B, P, 3, generator=gen) - 0.5)
+    radius = torch.tensor([1.0, 0.5, 2.0])
+    R = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))[0].contiguous()
+    t = (torch.rand(B, 3, generator=gen) - 0.5) * 0.1
+    l1 = (torch.rand(B, N, generator=gen) > 0.3).to(torch.int32)
+    thr = 0.03
+    d = [x.to(dev).contiguous() for x in (p1, R, t, model, radius, l1)]
+    cnt = torch.empty(2 * B, device=dev); score = torch.empty(B, device=dev)
+    tt = d[2].clone()
+    _lib.call("sam6d_fine_score", d[0].data_ptr(), d[1].data_ptr(), tt.data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), B, N, P,
+              thr, cnt.data_ptr(), score.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    x = (p1.double() - t.double().unsqueeze(1)) @ R.double()
+    m = model.double() / (radius.double().reshape(B, 1, 1) + 1e-6)
+    dis = torch.cdist(x, m).min(dim=2).values
+    mk = (l1 > 0).double()
+    lo = (((dis < thr - 1e-6).double() * mk).sum(1) / (mk.sum(1) + 1e-8)) * mk.mean(1)
+    hi = (((dis < thr + 1e-6).double() * mk).sum(1) / (mk.sum(1) + 1e-8)) * mk.mean(1)
+    got = score.cpu().double()
+    assert bool(((got >= lo - 1e-6) & (got <= hi + 1e-6)).all()), (got, lo, hi)
+    assert float((hi - lo).max()) < 0.02  # the band is a few threshold cases wide: the check is not vacuous
+    assert torch.allclose(tt.cpu(), t * (radius.reshape(B, 1) + 1e-6), rtol=1e-6, atol=0)
+
+
+def test_fine_score_matrix_core_kernel_equals_vector_kernel(dev, monkeypatch):
+    """The nearest-CAD-point count on the fp32 matrix cores (fine_near_mfma_kernel) and on the vector ALU (fine_near_kernel) evaluate the
+    same pairwise-distance bit recipe: identical counts, hence identical scores, at the step's shape."""
+    from sam6d_hip import _lib
+    gen = torch.Generator().manual_seed(77)
+    B, N, P = 4, 2048, 1024
+    p1 = (torch.rand(B, N, 3, generator=gen) - 0.5)
+    model = (torch.rand(B, P, 3, generator=gen) - 0.5)
+    radius = torch.tensor([1.0, 0.5, 2.0, 1.3])
+    R = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))[0].contiguous()
+    t = (torch.rand(B, 3, generator=gen) - 0.5) * 0.1
+    l1 = (torch.rand(B, N, generator=gen) > 0.3).to(torch.int32)
+    d = [x.to(dev).contiguous() for x in (p1, R, t, model, radius, l1)]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SAM6D_FINE_NEAR_MFMA", flag)
+        cnt = torch.empty(2 * B, device=dev); score = torch.empty(B, device=dev); tt = d[2].clone()
+        _lib.call("sam6d_fine_score", d[0].data_ptr(), d[1].data_ptr(), tt.data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(), B, N,
+                  P, 0.02, cnt.data_ptr(), score.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out[flag] = (cnt.cpu(), score.cpu())
+    assert torch.equal(out["1"][0], out["0"][0]) and torch.equal(out["1"][1], out["0"][1])
+    assert 0.0 < float(out["1"][1].min()) and float(out["1"][1].max()) < 1.0
+
+
 def test_procrustes_golden(dev):
     from sam6d_hip import pem
     g = golden("procrustes")
