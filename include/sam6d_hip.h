@@ -79,6 +79,13 @@ int sam6d_group_points(const float* points, const int* idx, int B, int C, int N,
 int sam6d_gather_rows(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b,
                       long out_stride_b, int idx_off, float* out, void* stream);
 
+/* The same with row 0 of every feats[b] supplied separately: lead[b] (rows lead_stride_b floats apart) stands for feats[b,0,:], which
+ * need not be written.  out[b,0,:] = lead[b,:], out[b,1+j,:] = feats[b, idx[b,j] + idx_off, :] (an index that lands on row 0 reads
+ * lead[b]) -- the sparse tokens of SparseToDenseTransformer in one launch: bg token + FPS rows of the cat [bg; dense]
+ * (PEM/model/transformer.py:667-705).  `out` rows 0 .. M. */
+int sam6d_gather_rows_lead(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b, long out_stride_b,
+                           int idx_off, const float* lead, long lead_stride_b, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * B2: building blocks of the PEM Python modules (CoarsePointMatching / FinePointMatching / GeometricTransformer /
  * model_utils).  The reference runs these as torch ops; here each is one or a few HIP launches.

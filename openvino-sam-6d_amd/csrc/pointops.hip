@@ -403,6 +403,46 @@ extern "C" int sam6d_gather_rows(const float* feats, const int* idx, int B, int 
   SAM6D_LAUNCH_CHECK("gather_rows");
 }
 
+// gather_rows with row 0 of every feats[b] supplied separately: `lead[b]` stands for feats[b, 0, :] (which need not be written), and
+// out[b,0,:] = lead[b,:], out[b,1+j,:] = feats[b, idx[b,j] + idx_off, :] -- the sparse tokens of a sparse-to-dense block (bg token + the
+// FPS rows of the dense tokens, PEM/model/transformer.py:667-705) in one launch instead of a gather and a one-row copy.
+__global__ void gather_rows_lead_kernel(const float* __restrict__ feats, const int* __restrict__ idx, int N, int M, int C,
+                                        long in_stride_b, long out_stride_b, int idx_off, const float* __restrict__ lead,
+                                        long lead_stride_b, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // output row 0 .. M
+  if (j > M) return;
+  bool ok = true;
+  const float* srow;
+  if (j == 0) {
+    srow = lead + (size_t)b * lead_stride_b;
+  } else {
+    const int a = idx[(size_t)b * M + j - 1] + idx_off;
+    ok = (a >= 0 && a < N);
+    // row 0 of feats[b] IS the lead row (the caller may not have written it into feats): the FPS indices address the cat [bg; dense]
+    // without the + 1 (the reference's quirk, transformer.py:667-705), and FPS always starts at index 0
+    srow = (ok && a > 0) ? feats + (size_t)b * in_stride_b + (size_t)a * C : lead + (size_t)b * lead_stride_b;
+  }
+  float* drow = out + (size_t)b * out_stride_b + (size_t)j * C;
+  const float4* src = reinterpret_cast<const float4*>(srow);
+  float4* dst = reinterpret_cast<float4*>(drow);
+  for (int c = (threadIdx.x & 63); c < C / 4; c += 64) dst[c] = ok ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int sam6d_gather_rows_lead(const float* feats, const int* idx, int B, int N, int M, int C, long in_stride_b,
+                                      long out_stride_b, int idx_off, const float* lead, long lead_stride_b, float* out,
+                                      void* stream) {
+  SAM6D_REQUIRE(feats && idx && out && lead, "gather_rows_lead: null pointer");
+  SAM6D_REQUIRE(B >= 0 && N > 0 && M >= 0 && C > 0 && (C & 3) == 0 && B <= 65535, "gather_rows_lead: bad sizes (C %% 4 == 0)");
+  SAM6D_REQUIRE(((in_stride_b | out_stride_b | lead_stride_b) & 3) == 0 && (((size_t)feats | (size_t)out | (size_t)lead) & 15) == 0,
+                "gather_rows_lead: 16-byte alignment required");
+  if (B == 0) return 0;
+  dim3 grid(cdiv(M + 1, 4), B);
+  hipLaunchKernelGGL(gather_rows_lead_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, idx, N, M, C, in_stride_b, out_stride_b,
+                     idx_off, lead, lead_stride_b, out);
+  SAM6D_LAUNCH_CHECK("gather_rows_lead");
+}
+
 // =========================================================================================================
 // Ball query (ball_query.cpp:16-62): per query, the first `nsample` indices k (increasing) with d2 < r*r; the first
 // hit pre-fills every slot; no hit -> zeros.  d2 in plain fp32, source order, no FMA.

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sam6d_ball_query2_grid": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_f, c_i, c_p, c_p, ctypes.c_size_t, c_p],
     "sam6d_group_points": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "sam6d_gather_rows": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_p],
+    "sam6d_gather_rows_lead": [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_p, c_l, c_p, c_p],
     "sam6d_gemm_nt": [c_p] * 6 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_gemm_nt_w16": [c_p] * 4 + [c_f] + [c_p] * 4 + [c_i] * 3 + [c_l] * 4 + [c_i] + [c_l] * 4 + [c_f, c_i, c_p],
     "sam6d_set_matmul_mode": [c_i],

@@ -1019,18 +1019,22 @@ def linear_transformer_layer(D, S, L):
 
 
 @on_tensor_device
-def sparse_to_dense_transformer(D, E, fps_idx, T):
+def sparse_to_dense_transformer(D, E, fps_idx, T, lead=None, write_bg=True, return_sparse=False):
     """D (2B,N+1,256) dense tokens incl. bg row, E (2B,n,n,256), fps_idx (2B,n-1) i32 -> new D
-    (SparseToDenseTransformer, PEM/model/transformer.py:627-720, incl. the index-into-the-cat quirk :667-705)."""
+    (SparseToDenseTransformer, PEM/model/transformer.py:627-720, incl. the index-into-the-cat quirk :667-705).
+    lead: (2B, >=1, 256) tensor whose row 0 per cloud is the bg token of D (default: D itself).  Between the blocks of the fine stage
+    nothing reads row 0 of D but the next block's gather, so fine_point_matching hands the previous block's sparse tokens on as `lead`
+    and writes the bg row of D (write_bg) after the last block only: one small launch per block instead of three."""
     Bp, I, _ = D.shape
     n1 = fps_idx.shape[1]
     S = _empty((Bp, n1 + 1, C), D)
-    _lib.call("sam6d_gather_rows", _p(D), _p(fps_idx), Bp, I, n1, C, I * C, (n1 + 1) * C, 0, _p(S, C), _s())
-    _lib.call("sam6d_put_rows", _p(D), I * C, C, _p(S), (n1 + 1) * C, C, Bp, 1, C, _s())
+    ld = D if lead is None else lead
+    _lib.call("sam6d_gather_rows_lead", _p(D), _p(fps_idx), Bp, I, n1, C, I * C, (n1 + 1) * C, 0, _p(ld), ld.shape[1] * C, _p(S), _s())
     S = geometric_transformer(S, E, T)
     Dn = linear_transformer_layer(D, S, T["dense"])
-    _lib.call("sam6d_put_rows", _p(S), (n1 + 1) * C, C, _p(Dn), I * C, C, Bp, 1, C, _s())
-    return Dn
+    if write_bg:
+        _lib.call("sam6d_put_rows", _p(S), (n1 + 1) * C, C, _p(Dn), I * C, C, Bp, 1, C, _s())
+    return (Dn, S) if return_sparse else Dn
 
 
 def pe_group(pts, r1=0.1, r2=0.2, ns1=32, ns2=64):
@@ -1394,8 +1398,10 @@ def fine_point_matching(dp, df, E, fps_idx, radius, model, init_R, init_t, W, cf
     _lib.call("sam6d_rigid_inverse", _p(dp), _p(init_R), _p(init_t), B, N, _p(p1), _s())  # p1_ = (p1 - t) @ R
     positional_encoding_add(p1, W, D, C, (N + 1) * C, cfg["pe_radius1"], cfg["pe_radius2"], cfg["pe_nsample1"],
                             cfg["pe_nsample2"])
-    for blk in W.fine["blocks"]:
-        D = sparse_to_dense_transformer(D, E, fps_idx, blk)
+    blocks = W.fine["blocks"]
+    lead = None
+    for k, blk in enumerate(blocks):
+        D, lead = sparse_to_dense_transformer(D, E, fps_idx, blk, lead=lead, write_bg=(k == len(blocks) - 1), return_sparse=True)
     if fused_fine and N in (2048, 4096) and _fused_block():
         # similarity + soft assignment as one pipeline: the (B, 2049, 2049) matrix is written once and read twice (finematch.hip)
         if _flags().fused_out and _flags().mode >= 1:

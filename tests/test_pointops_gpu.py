@@ -101,6 +101,33 @@ def test_fps_duplicate_points_tie_break(dev, ext):
     assert torch.equal(ext.furthest_point_sampling(xyz.to(dev), 40).cpu(), P.furthest_point_sampling(xyz, 40))
 
 
+def test_gather_rows_lead(dev):
+    """sam6d_gather_rows_lead: row 0 of every feats[b] is supplied by `lead` -- out row 0 and every gathered index 0 read it (feats row 0
+    holds garbage here), out-of-range indices give zeros, the other rows are plain gathers."""
+    from sam6d_hip import _lib
+    gen = torch.Generator().manual_seed(12)
+    B, N, M, Cc = 3, 50, 9, 256
+    feats = torch.randn(B, N, Cc, generator=gen)
+    lead = torch.randn(B, 4, Cc, generator=gen)  # row 0 of each block is the lead row
+    idx = torch.randint(1, N, (B, M), generator=gen, dtype=torch.int32)
+    idx[:, 0] = 0
+    idx[1, 3] = N + 5
+    idx[2, 4] = -2
+    want = torch.zeros(B, M + 1, Cc)
+    for b in range(B):
+        want[b, 0] = lead[b, 0]
+        for j in range(M):
+            a = int(idx[b, j])
+            want[b, 1 + j] = lead[b, 0] if a == 0 else (feats[b, a] if 0 < a < N else 0.0)
+    f = feats.clone(); f[:, 0] = float("nan")
+    fd, ld, idd = f.to(dev), lead.to(dev), idx.to(dev)
+    out = torch.empty(B, M + 1, Cc, device=dev)
+    _lib.call("sam6d_gather_rows_lead", fd.data_ptr(), idd.data_ptr(), B, N, M, Cc, N * Cc, (M + 1) * Cc, 0, ld.data_ptr(), 4 * Cc,
+              out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+
+
 def test_gather_golden(dev, ext):
     g = golden("pointops")
     gen = torch.Generator().manual_seed(11)
